@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- examples/sec of the FNN hot path on N MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): FNN L3, 16 fields, 937,670 one-hot
+dims, k=10 (row width K=11), hidden 300/100 tanh, batch 4096 per GPU, bf16 MFMA with f32
+accumulation and f32 master weights, synthetic Zipf(1.1) ids, inputs resident in HBM.
+A "step" is one pass of the reference's hot loop body (python/FNN_wnzh.py:296-306): gather ->
+train(x, y) -> dense SGD -> sparse-row SGD, for one batch, through the C ABI of libfnn_hip.so.
+N > 1: one process per GPU (torch.distributed.run), batch sharded data-parallel (weak scaling:
+4096 examples per GPU), one RCCL all-reduce of the flat dense-gradient bucket per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F, K, H1, H2 = 16, 11, 300, 100
+XDIM = 1 + F * K
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+
+# ALGORITHMIC bytes / flops per example of each kernel
+ALGO = {
+    'gather':   ('hbm', 64 + 704 + 708),                 # ids + 16 rows of 44 B + x (177 f32)
+    'scatter':  ('hbm', 704 + 704 + 704 + 64),           # gx + row read + row write + ids (scatter+finalize)
+    'fwd1':     ('mfma', 2 * XDIM * H1),
+    'fwd2':     ('mfma', 2 * H1 * H2),
+    'bwd1':     ('mfma', 2 * H1 * H2),
+    'gx':       ('mfma', 2 * XDIM * H1),
+    'wgrad':    ('mfma', 2 * (XDIM * H1 + H1 * H2)),
+    'head':     ('hbm', H2 * 2 * 3 + 8),                 # d2 read, delta2 written in two layouts, y, p
+}
+STEP_MIN_BYTES = 2180                                    # fused train-step minimum, B/example
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import _capi, synth
+    from deep_ctr_amd import dl_utils as ut
+    from deep_ctr_amd.engine import FNNEngine
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    B = args.batch
+    NB = 32                                               # distinct resident batches, cycled
+
+    # ---- synthetic workload, seeded (table identical on every rank; ids differ per rank)
+    sizes = synth.field_sizes_ipinyou()
+    rows = synth.fm_table(sum(sizes), K, 0.05, 1234)
+    fo = synth.field_of_row(sizes)
+    ids_np = synth.zipf_ids(NB * B, sizes, 1.1, 1234 + 1000 * rank)
+    y_np = (np.random.RandomState(99 + rank).uniform(size=NB * B) < 0.02).astype(np.float32)
+    ut.seed_global(1234)
+    p0 = ut.init_fnn_weights(XDIM, H1, H2, 'tanh')
+    srng = ut.RandomStreams(234)
+    srng.binomial(size=(1, XDIM), n=1, p=1)
+    o1 = srng.binomial(size=(NB, H1), n=1, p=0.5)
+    o2 = srng.binomial(size=(NB, H2), n=1, p=0.5)
+    m1_np = o1.draw().astype(np.uint8)
+    m2_np = o2.draw().astype(np.uint8)
+
+    eng = FNNEngine(F, K, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
+                    lambda_fm=0.1, device=local_rank)
+    eng.set_table(rows, fo, -3.0)
+    eng.set_dense(p0)
+    ids = torch.as_tensor(ids_np).to(dev).contiguous()
+    y = torch.as_tensor(y_np).to(dev).contiguous()
+    m1 = torch.as_tensor(m1_np).to(dev).contiguous()
+    m2 = torch.as_tensor(m2_np).to(dev).contiguous()
+    torch.cuda.synchronize(dev)
+    lib, h = eng.lib, eng.h
+    gB = B * world
+    bucket = eng.grad_bucket()
+
+    def step(i):
+        b = i % NB
+        a = (h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, m1.data_ptr() + b * H1,
+             m2.data_ptr() + b * H2, gB)
+        if world == 1:
+            rc = lib.fnn_train_step(*a, None, None, _capi.FNN_MEM_DEVICE, None)
+        else:
+            rc = lib.fnn_step_begin(*a, None, None, _capi.FNN_MEM_DEVICE)
+            if rc == 0:
+                dist.all_reduce(bucket)                  # RCCL, ordered on the engine's stream
+                rc = lib.fnn_step_end(h, None)
+        if rc != 0:
+            raise RuntimeError(lib.fnn_last_error(h).decode())
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(eng.stream):
+        for i in range(args.warmup):
+            step(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        sync_all()
+        dt = time.perf_counter() - t0
+    eng.sync()
+    last_loss = eng.last_loss() / B
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = gB * args.steps / dt
+
+    # ---- per-kernel device time (HIP events on the library's own streams), same step loop
+    roofline = None
+    kern_ms = {}
+    if rank == 0:
+        eng.prof_enable(True)
+        eng.prof_reset()
+        with torch.cuda.stream(eng.stream):
+            for i in range(min(args.steps, 100)):
+                step(i)
+        torch.cuda.synchronize(dev)
+        for name in ('gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
+                     'scatter', 'finalize'):
+            kern_ms[name] = eng.prof_get(name)[0]
+        eng.prof_enable(False)
+        merged = dict(kern_ms)
+        merged['scatter'] = kern_ms['scatter'] + kern_ms['finalize']
+        cand = {k: v for k, v in merged.items() if k in ALGO}
+        dom = max(cand, key=cand.get)
+        bound, per_ex = ALGO[dom]
+        t_s = cand[dom] * 1e-3
+        if bound == 'hbm':
+            ach = per_ex * B / t_s / 1e9
+            peak, unit = HBM_PEAK_GBS, 'GB/s'
+        else:
+            ach = per_ex * B / t_s / 1e12
+            peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
+        roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
+                    'frac': ach / peak, 'traffic': None, 'avg_launch_ms': cand[dom],
+                    'algorithmic_per_example': per_ex,
+                    'gather': {'achieved': ALGO['gather'][1] * B / (kern_ms['gather'] * 1e-3) / 1e9,
+                               'frac': ALGO['gather'][1] * B / (kern_ms['gather'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               'unit': 'GB/s', 'avg_launch_ms': kern_ms['gather']},
+                    'step': {'achieved': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9,
+                             'frac': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'unit': 'GB/s'}}
+
+    # ---- CPU baseline: the C port of the oracle on this host, 1 core, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            'metric': 'examples/sec', 'value': value, 'unit': 'examples/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'FNN L3 train step: 16 fields, 937670 one-hot dims, k=10, hidden 300/100 '
+                                   'tanh, batch 4096 per GPU, Zipf(1.1) ids',
+                       'per_gpu_batch': B, 'global_batch': gB,
+                       'parallelism': 'dp%d' % world if world > 1 else 'single'},
+            'train_logloss_last_step': last_loss,
+            'roofline': roofline, 'cpu_baseline': cpu, 'kernel_ms': kern_ms,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, seconds):
+    """Times oracle/fnn_oracle.c (float64, scalar, 1 thread) on the same table / ids."""
+    import __graft_entry__ as g
+    if not os.path.exists(g.ORACLE_LIB):
+        g.build()
+    lib = C.CDLL(g.ORACLE_LIB)
+
+    class Cfg(C.Structure):
+        _fields_ = [("F", C.c_int), ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("lr", C.c_double),
+                    ("lambda1", C.c_double), ("lambda_fm", C.c_double), ("w0", C.c_double)]
+    lib.oracle_train_step.restype = C.c_double
+    cfg = Cfg(F, K, H1, H2, 0.001, 0.0, 0.1, -3.0)
+    rows64 = np.ascontiguousarray(rows, dtype=np.float64)
+    w = {k: np.ascontiguousarray(np.array(v, dtype=np.float64)) for k, v in p0.items() if k != 'b3'}
+    b3 = C.c_double(0.0)
+    dp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    n, t0 = 0, time.perf_counter()
+    while True:
+        b = n % (len(y_np) // B)
+        sl = slice(b * B, (b + 1) * B)
+        ids = np.ascontiguousarray(ids_np[sl]); yy = np.ascontiguousarray(y_np[sl], dtype=np.float64)
+        r1 = np.ascontiguousarray(m1_np[b], dtype=np.float64); r2 = np.ascontiguousarray(m2_np[b], dtype=np.float64)
+        lib.oracle_train_step(C.byref(cfg), dp(rows64), dp(ids), dp(yy), B, dp(r1), dp(r2), B, dp(w['w1']),
+                              dp(w['b1']), dp(w['w2']), dp(w['b2']), dp(w['w3']), C.byref(b3), None, None)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {'value': n * B / el, 'unit': 'examples/sec', 'cores': 1, 'kind': 'port',
+            'sample': '%d steps of batch %d on the same table/ids (oracle/fnn_oracle.c, float64, scalar; host has '
+                      '%d cores)' % (n, B, os.cpu_count())}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,76 @@
+"""ctypes binding of libfnn_hip.so (C ABI: include/fnn_hip.h).
+
+This is the same stub a maintainer of the reference would add next to `FNN_wnzh.py` to replace
+`theano.function` (python/FNN_wnzh.py:177-183); see INTEGRATION.md.  The library is looked up
+in-tree (deep-ctr_amd/libfnn_hip.so, built by `__graft_entry__.build()`); a missing library is
+an ImportError-class failure, never a silent fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfnn_hip.so")
+
+FNN_OK = 0
+FNN_ERR_ARG, FNN_ERR_HIP, FNN_ERR_STATE, FNN_ERR_RANGE, FNN_ERR_NOMEM = -1, -2, -3, -4, -5
+FNN_PREC_F32, FNN_PREC_BF16 = 0, 1
+FNN_ACT_TANH, FNN_ACT_SIGMOID, FNN_ACT_LINEAR = 0, 1, 2
+FNN_MEM_HOST, FNN_MEM_DEVICE = 0, 1
+
+
+class fnn_cfg(C.Structure):
+    _fields_ = [("n_fields", C.c_int32), ("k", C.c_int32), ("hidden1", C.c_int32),
+                ("hidden2", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32),
+                ("act", C.c_int32), ("reg_all", C.c_int32), ("lr", C.c_float),
+                ("lambda1", C.c_float), ("lambda_fm", C.c_float), ("device", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes): every symbol include/fnn_hip.h declares
+SIGNATURES = {
+    "fnn_version": (C.c_char_p, []),
+    "fnn_last_error": (C.c_char_p, [_vp]),
+    "fnn_create": (_i, [C.POINTER(fnn_cfg), C.POINTER(_vp)]),
+    "fnn_destroy": (_i, [_vp]),
+    "fnn_set_hparams": (_i, [_vp, _f, _f, _f]),
+    "fnn_stream": (_vp, [_vp]),
+    "fnn_sync": (_i, [_vp]),
+    "fnn_set_table": (_i, [_vp, _vp, _i64, _vp, _f, _i]),
+    "fnn_get_table": (_i, [_vp, _vp, _i]),
+    "fnn_get_rows": (_i, [_vp, _vp, _i64, _vp, _i]),
+    "fnn_set_dense": (_i, [_vp, _i, _vp, _vp, _i]),
+    "fnn_get_dense": (_i, [_vp, _i, _vp, _vp, _i]),
+    "fnn_gather": (_i, [_vp, _vp, _i, _vp, _i]),
+    "fnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.POINTER(_f)]),
+    "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
+    "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "fnn_step_end": (_i, [_vp, C.POINTER(_f)]),
+    "fnn_last_loss": (_i, [_vp, C.POINTER(_f)]),
+    "fnn_predict": (_i, [_vp, _vp, _i, _vp, _i]),
+    "fnn_prof_enable": (_i, [_vp, _i]),
+    "fnn_prof_reset": (_i, [_vp]),
+    "fnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfnn_hip.so and declare every prototype.  Raises if the library is missing:
+    the product path has no other backend."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libfnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

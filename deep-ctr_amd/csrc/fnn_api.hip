@@ -1,0 +1,656 @@
+// fnn_api.hip -- host side of libfnn_hip.so: the C ABI declared in include/fnn_hip.h.
+// Replaces the compiled Theano callables `train` / `predict` (python/FNN_wnzh.py:177-183 of
+// Atomu2014/deep-ctr) and the Python gather / sparse-update loops around them (:87-96, :299-306).
+// gfx950 only; there is no CPU fallback: without a HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fnn_hip.h"
+#include "fnn_kernels.hip.h"
+
+using namespace fnn;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; int64_t n = 0; };
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct fnn_handle {
+    fnn_cfg cfg{};
+    std::string err;
+    int dev = 0;
+    hipStream_t st = nullptr, st_side = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // shapes
+    int F = 0, K = 0, H1 = 0, H2 = 0, xdim = 0, K1p = 0, H1p = 0, H2p = 0;
+    int Bmax = 0, ldT = 0, N2max = 0;
+    size_t n1 = 0, n2 = 0, nw12 = 0, nw = 0;
+    int splitk = 8;
+    bool bf16 = false;
+    // FM table
+    float* table16 = nullptr; int32_t* field_of_row = nullptr; int64_t n_rows = 0; float w0 = 0.f;
+    // dense
+    float* master = nullptr; float* bucket = nullptr; float* slab = nullptr;
+    void *w1 = nullptr, *w1t = nullptr, *w2 = nullptr, *w2t = nullptr;   // shadows (T)
+    bool dense_set[3] = {false, false, false};
+    // activations (T) and f32 work buffers
+    void *xp = nullptr, *xpT = nullptr, *d1 = nullptr, *d1T = nullptr, *d2 = nullptr, *dl2 = nullptr,
+         *dl2T = nullptr, *dl1 = nullptr, *dl1T = nullptr;
+    float *gxp = nullptr, *p_buf = nullptr, *gw3_part = nullptr, *loss_part = nullptr, *loss_dev = nullptr;
+    int nblk_head_max = 0;
+    // scatter
+    int4* rec = nullptr; unsigned long long* accum = nullptr; double* cpow_dev = nullptr;
+    std::vector<double> cpow_host; double cpow_c = -1.0; int cpow_n = 0;
+    int* err_flag = nullptr;
+    // host-pointer staging
+    int32_t* st_ids = nullptr; float* st_y = nullptr; uint8_t* st_m1 = nullptr; uint8_t* st_m2 = nullptr;
+    float* st_p = nullptr; float* st_x = nullptr;
+    // step state
+    bool in_step = false; int step_B = 0;
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfSlot> prof_slots;
+};
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return FNN_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+#define FAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
+
+namespace {
+
+struct ProfScope {
+    fnn_handle* h; hipStream_t s; hipEvent_t b = nullptr, e = nullptr; const char* name;
+    ProfScope(fnn_handle* h_, const char* n, hipStream_t s_) : h(h_), s(s_), name(n) {
+        if (!h->prof) return;
+        hipEventCreate(&b); hipEventCreate(&e); hipEventRecord(b, s);
+    }
+    ~ProfScope() {
+        if (!h->prof) return;
+        hipEventRecord(e, s);
+        h->prof_slots[name].ev.emplace_back(b, e);
+    }
+};
+
+template <typename T> int alloc_dev(fnn_handle* h, T** p, size_t n, bool zero = true) {
+    HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+    if (zero) HIPCHK(h, hipMemsetAsync(*p, 0, n * sizeof(T), h->st));
+    return FNN_OK;
+}
+
+size_t tsize(const fnn_handle* h) { return h->bf16 ? 2 : 4; }
+
+int check_async(fnn_handle* h) {
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (flag) {
+        HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), h->st));
+        FAIL(h, FNN_ERR_RANGE, "feature id outside [-1, n_rows) (reference: KeyError, python/FNN_wnzh.py:95)");
+    }
+    return FNN_OK;
+}
+
+int update_cpow(fnn_handle* h, int b_size, int B) {
+    const double c = 1.0 - 2.0 * (double)h->cfg.lambda_fm * (double)h->cfg.lr / (double)b_size;
+    if (c == h->cpow_c && h->cpow_n >= B + 1) return FNN_OK;
+    // in-flight kernels may still read the old table
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    const int n = h->N2max + 1;
+    h->cpow_host.resize(n);
+    for (int i = 0; i < n; ++i) h->cpow_host[i] = std::pow(c, (double)i);
+    HIPCHK(h, hipMemcpy(h->cpow_dev, h->cpow_host.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    h->cpow_c = c; h->cpow_n = n;
+    return FNN_OK;
+}
+
+template <typename T, int NT, typename Epi>
+void launch_gemm(hipStream_t s, const T* A, int lda, const T* Bt, int ldb, int M, int N, int klen,
+                 int splitk, Epi epi) {
+    dim3 grid(M / 64, N / (16 * NT), splitk);
+    hipLaunchKernelGGL((k_gemm<T, NT, Epi>), grid, dim3(256), 0, s, A, lda, Bt, ldb, klen, epi);
+}
+
+// refresh shadows from the masters without a gradient step
+template <typename T> void launch_update(fnn_handle* h, const float* bucket, float lr) {
+    const size_t n = h->nw;
+    hipLaunchKernelGGL((k_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->master,
+                       bucket, lr, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t);
+}
+
+// gather + forward (+ backward when train).  Everything on h->st except the id sort.
+template <typename T>
+int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* m1,
+             const uint8_t* m2, bool train, float* p_out, float* gx_out_dev)
+{
+    const int Ba = rup(B, 256);
+    const int F = h->F, K = h->K, K1p = h->K1p, H1p = h->H1p, H2p = h->H2p, ldT = h->ldT;
+    T *xp = (T*)h->xp, *xpT = (T*)h->xpT, *d1 = (T*)h->d1, *d1T = (T*)h->d1T, *d2 = (T*)h->d2,
+      *dl2 = (T*)h->dl2, *dl2T = (T*)h->dl2T, *dl1 = (T*)h->dl1, *dl1T = (T*)h->dl1T;
+    int N2 = 64; while (N2 < B) N2 <<= 1;
+
+    if (train) {   // A6 part 1: the sort only needs the ids; run it beside the MLP
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
+        HIPCHK(h, hipStreamWaitEvent(h->st_side, h->ev_fork, 0));
+        {
+            ProfScope ps(h, "sort", h->st_side);
+            hipLaunchKernelGGL(k_sort, dim3(F), dim3(1024), (size_t)N2 * 8, h->st_side, ids, B, F,
+                               h->n_rows, N2, h->rec);
+        }
+        HIPCHK(h, hipEventRecord(h->ev_join, h->st_side));
+    }
+    {   // A3
+        ProfScope ps(h, "gather", h->st);
+        const int nthreads = Ba * F;
+        hipLaunchKernelGGL((k_gather<T>), dim3((nthreads + 255) / 256), dim3(256), 0, h->st, ids, B, Ba,
+                           F, K, h->table16, h->n_rows, h->w0, xp, K1p, xpT, ldT, h->err_flag);
+    }
+    {   // A4 layer 1: d1 = act(x' W1p) * r1
+        ProfScope ps(h, "fwd1", h->st);
+        EpiFwd<T> e{d1, H1p, train ? d1T : nullptr, ldT, m1, h->cfg.act, h->H1, B};
+        launch_gemm<T, 4>(h->st, xp, K1p, (const T*)h->w1t, K1p, Ba, H1p, K1p, 1, e);
+    }
+    {   // A4 layer 2: d2 = tanh(d1 W2p) * r2   (predict: acti_type, no mask)
+        ProfScope ps(h, "fwd2", h->st);
+        EpiFwd<T> e{d2, H2p, nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
+        launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, H1p, Ba, H2p, H1p, 1, e);
+    }
+    {   // output unit, loss, delta2
+        ProfScope ps(h, "head", h->st);
+        hipLaunchKernelGGL((k_head<T>), dim3(Ba / 64), dim3(256), 0, h->st, d2, H2p, h->H2,
+                           h->master + h->nw12, m2, y, B, train ? 1 : 0, p_out, dl2, dl2T, ldT,
+                           h->gw3_part, h->loss_part);
+    }
+    if (!train) return FNN_OK;
+    {   // A5: delta1 = (delta2 W2p^T) * r1 * act'(d1)
+        ProfScope ps(h, "bwd1", h->st);
+        EpiBwd<T> e{dl1, H1p, dl1T, ldT, d1, m1, h->cfg.act, h->H1, B};
+        launch_gemm<T, 4>(h->st, dl2, H2p, (const T*)h->w2, H2p, Ba, H1p, H2p, 1, e);
+    }
+    {   // A5: gx' = delta1 W1p^T
+        ProfScope ps(h, "gx", h->st);
+        EpiF32 e{h->gxp, K1p, 0};
+        launch_gemm<T, 4>(h->st, dl1, H1p, (const T*)h->w1, H1p, Ba, K1p, H1p, 1, e);
+    }
+    {   // A5: dense gradients, contraction over the examples, split-K slabs
+        ProfScope ps(h, "wgrad", h->st);
+        const int klen = Ba / h->splitk;
+        EpiF32 e1{h->slab, H1p, h->nw12};
+        launch_gemm<T, 4>(h->st, xpT, ldT, dl1T, ldT, K1p, H1p, klen, h->splitk, e1);
+        EpiF32 e2{h->slab + h->n1, H2p, h->nw12};
+        launch_gemm<T, 4>(h->st, d1T, ldT, dl2T, ldT, H1p, H2p, klen, h->splitk, e2);
+    }
+    {
+        ProfScope ps(h, "reduce", h->st);
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((h->nw + 255) / 256)), dim3(256), 0, h->st, h->slab,
+                           h->splitk, h->nw, h->nw12, h->gw3_part, Ba / 64, H2p, h->master,
+                           h->cfg.lambda1, h->cfg.reg_all, h->loss_part, h->bucket, h->loss_dev);
+    }
+    if (gx_out_dev) {
+        const size_t n = (size_t)B * h->xdim;
+        hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, K1p,
+                           B, F, K, gx_out_dev);
+    }
+    // A6 part 2
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));
+    const size_t nthr = (size_t)F * N2 * 4;
+    {
+        ProfScope ps(h, "scatter", h->st);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec, N2,
+                           F, K, h->gxp, K1p, h->cpow_dev, (double)h->cfg.lr, h->accum);
+    }
+    {
+        ProfScope ps(h, "finalize", h->st);
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec,
+                           N2, F, K, h->cpow_dev, h->accum, h->table16);
+    }
+    HIPCHK(h, hipGetLastError());
+    return FNN_OK;
+}
+
+int check_ready(fnn_handle* h, int B) {
+    if (!h) return FNN_ERR_ARG;
+    if (B <= 0 || B > h->Bmax) FAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
+    if (!h->table16) FAIL(h, FNN_ERR_STATE, "fnn_set_table has not been called");
+    if (!(h->dense_set[0] && h->dense_set[1] && h->dense_set[2]))
+        FAIL(h, FNN_ERR_STATE, "fnn_set_dense has not been called for all three layers");
+    return FNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fnn_version(void) { return "fnn_hip 0.1 (gfx950)"; }
+
+const char* fnn_last_error(const fnn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return FNN_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->n_fields < 2 || cfg->n_fields > 64) { g_create_err = "n_fields must be in [2, 64]"; return FNN_ERR_ARG; }
+    if (cfg->k < 1 || cfg->k > 15) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
+    if (cfg->hidden1 < 1 || cfg->hidden1 > 4095 || cfg->hidden2 < 1 || cfg->hidden2 > 255) { g_create_err = "hidden1 must be in [1, 4095], hidden2 in [1, 255]"; return FNN_ERR_ARG; }
+    if (cfg->max_batch < 1 || cfg->max_batch > 16384) { g_create_err = "max_batch must be in [1, 16384] (per-field LDS sort)"; return FNN_ERR_ARG; }
+    if (cfg->precision != FNN_PREC_F32 && cfg->precision != FNN_PREC_BF16) { g_create_err = "bad precision"; return FNN_ERR_ARG; }
+    if (cfg->act < 0 || cfg->act > 2) { g_create_err = "bad act"; return FNN_ERR_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device: ") + hipGetErrorString(e) + " (libfnn_hip.so has no CPU fallback)";
+        return FNN_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "device ordinal out of range"; return FNN_ERR_ARG; }
+    fnn_handle* h = new fnn_handle();
+    h->cfg = *cfg; h->dev = cfg->device;
+    auto fail = [&](int code) { g_create_err = h->err; fnn_destroy(h); return code; };
+#define CK(expr) do { int rc_ = (expr); if (rc_ != FNN_OK) return fail(rc_); } while (0)
+#define HK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e2_); return fail(FNN_ERR_HIP); } } while (0)
+    HK(hipSetDevice(h->dev));
+    if (cfg->stream) { h->st = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else { HK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking)); h->own_stream = true; }
+    HK(hipStreamCreateWithFlags(&h->st_side, hipStreamNonBlocking));
+    HK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    h->F = cfg->n_fields; h->K = cfg->k; h->H1 = cfg->hidden1; h->H2 = cfg->hidden2;
+    h->xdim = 1 + h->F * h->K;
+    h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
+    h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
+    h->N2max = 64; while (h->N2max < h->Bmax) h->N2max <<= 1;
+    h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
+    h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
+    h->bf16 = cfg->precision == FNN_PREC_BF16;
+    const size_t ts = tsize(h), Ba = h->ldT;
+    CK(alloc_dev(h, &h->master, h->nw));
+    CK(alloc_dev(h, &h->bucket, h->nw));
+    CK(alloc_dev(h, &h->slab, (size_t)h->splitk * h->nw12));
+    CK(alloc_dev(h, (char**)&h->w1, h->n1 * ts));   CK(alloc_dev(h, (char**)&h->w1t, h->n1 * ts));
+    CK(alloc_dev(h, (char**)&h->w2, h->n2 * ts));   CK(alloc_dev(h, (char**)&h->w2t, h->n2 * ts));
+    CK(alloc_dev(h, (char**)&h->xp, Ba * h->K1p * ts));  CK(alloc_dev(h, (char**)&h->xpT, Ba * h->K1p * ts));
+    CK(alloc_dev(h, (char**)&h->d1, Ba * h->H1p * ts));  CK(alloc_dev(h, (char**)&h->d1T, Ba * h->H1p * ts));
+    CK(alloc_dev(h, (char**)&h->dl1, Ba * h->H1p * ts)); CK(alloc_dev(h, (char**)&h->dl1T, Ba * h->H1p * ts));
+    CK(alloc_dev(h, (char**)&h->d2, Ba * h->H2p * ts));
+    CK(alloc_dev(h, (char**)&h->dl2, Ba * h->H2p * ts)); CK(alloc_dev(h, (char**)&h->dl2T, Ba * h->H2p * ts));
+    CK(alloc_dev(h, &h->gxp, Ba * h->K1p));
+    CK(alloc_dev(h, &h->p_buf, Ba));
+    h->nblk_head_max = (int)(Ba / 64);
+    CK(alloc_dev(h, &h->gw3_part, (size_t)h->nblk_head_max * h->H2p));
+    CK(alloc_dev(h, &h->loss_part, (size_t)h->nblk_head_max));
+    CK(alloc_dev(h, &h->loss_dev, (size_t)1));
+    CK(alloc_dev(h, &h->rec, (size_t)h->F * h->N2max));
+    CK(alloc_dev(h, &h->accum, (size_t)h->F * h->N2max * SLOT));
+    CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
+    CK(alloc_dev(h, &h->err_flag, (size_t)1));
+    CK(alloc_dev(h, &h->st_ids, (size_t)h->Bmax * h->F));
+    CK(alloc_dev(h, &h->st_y, (size_t)h->Bmax));
+    CK(alloc_dev(h, &h->st_m1, (size_t)h->H1p)); CK(alloc_dev(h, &h->st_m2, (size_t)h->H2p));
+    CK(alloc_dev(h, &h->st_p, (size_t)h->Bmax));
+    CK(alloc_dev(h, &h->st_x, (size_t)h->Bmax * h->xdim));
+    if ((size_t)h->N2max * 8 > 48 * 1024)
+        HK(hipFuncSetAttribute((const void*)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
+    HK(hipStreamSynchronize(h->st));
+#undef CK
+#undef HK
+    *out = h;
+    return FNN_OK;
+}
+
+int fnn_destroy(fnn_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    hipSetDevice(h->dev);
+    if (h->st) hipStreamSynchronize(h->st);
+    if (h->st_side) hipStreamSynchronize(h->st_side);
+    for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
+                    h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
+                    h->gw3_part, h->loss_part, h->loss_dev, h->rec, h->accum, h->cpow_dev, h->err_flag,
+                    h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->st_side) hipStreamDestroy(h->st_side);
+    if (h->own_stream && h->st) hipStreamDestroy(h->st);
+    delete h;
+    return FNN_OK;
+}
+
+int fnn_set_hparams(fnn_handle* h, float lr, float lambda1, float lambda_fm)
+{
+    if (!h) return FNN_ERR_ARG;
+    h->cfg.lr = lr; h->cfg.lambda1 = lambda1; h->cfg.lambda_fm = lambda_fm;
+    return FNN_OK;
+}
+
+void* fnn_stream(fnn_handle* h) { return h ? (void*)h->st : nullptr; }
+
+int fnn_sync(fnn_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->st_side));
+    return check_async(h);
+}
+
+int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows, const int32_t* field_of_row,
+                  float w0, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!rows || n_rows <= 0 || n_rows >= (1ll << 31)) FAIL(h, FNN_ERR_ARG, "rows null or n_rows out of range");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (h->table16) { hipFree(h->table16); h->table16 = nullptr; }
+    if (h->field_of_row) { hipFree(h->field_of_row); h->field_of_row = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->table16, (size_t)n_rows * SLOT * sizeof(float)));
+    HIPCHK(h, hipMalloc((void**)&h->field_of_row, (size_t)n_rows * sizeof(int32_t)));
+    const size_t nbytes = (size_t)n_rows * h->K * sizeof(float);
+    const float* src = rows; float* tmp = nullptr;
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMalloc((void**)&tmp, nbytes));
+        HIPCHK(h, hipMemcpy(tmp, rows, nbytes, hipMemcpyHostToDevice));
+        src = tmp;
+    }
+    const size_t n = (size_t)n_rows * SLOT;
+    hipLaunchKernelGGL(k_pack_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, src, n_rows, h->K, h->table16);
+    if (field_of_row)
+        HIPCHK(h, hipMemcpyAsync(h->field_of_row, field_of_row, (size_t)n_rows * sizeof(int32_t),
+                                 memkind == FNN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
+    else
+        HIPCHK(h, hipMemsetAsync(h->field_of_row, 0, (size_t)n_rows * sizeof(int32_t), h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (tmp) hipFree(tmp);
+    h->n_rows = n_rows; h->w0 = w0;
+    return FNN_OK;
+}
+
+static int get_rows_impl(fnn_handle* h, const int64_t* row_ids, int64_t n, float* out, int memkind)
+{
+    if (!h->table16) FAIL(h, FNN_ERR_STATE, "fnn_set_table has not been called");
+    if (!out || n <= 0) FAIL(h, FNN_ERR_ARG, "out null or n <= 0");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const size_t cnt = (size_t)n * h->K;
+    const int64_t* ids_dev = row_ids; float* out_dev = out;
+    int64_t* tmp_ids = nullptr; float* tmp_out = nullptr;
+    if (memkind == FNN_MEM_HOST) {
+        if (row_ids) {
+            HIPCHK(h, hipMalloc((void**)&tmp_ids, (size_t)n * sizeof(int64_t)));
+            HIPCHK(h, hipMemcpy(tmp_ids, row_ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+            ids_dev = tmp_ids;
+        }
+        HIPCHK(h, hipMalloc((void**)&tmp_out, cnt * sizeof(float)));
+        out_dev = tmp_out;
+    }
+    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->st, h->table16,
+                       ids_dev, n, h->n_rows, h->K, out_dev, h->err_flag);
+    int rc = FNN_OK;
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(out, tmp_out, cnt * sizeof(float), hipMemcpyDeviceToHost, h->st));
+        rc = check_async(h);
+        if (tmp_ids) hipFree(tmp_ids);
+        hipFree(tmp_out);
+    }
+    return rc;
+}
+
+int fnn_get_table(fnn_handle* h, float* rows_out, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    return get_rows_impl(h, nullptr, h->n_rows, rows_out, memkind);
+}
+
+int fnn_get_rows(fnn_handle* h, const int64_t* row_ids, int64_t n, float* out, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!row_ids) FAIL(h, FNN_ERR_ARG, "row_ids null");
+    return get_rows_impl(h, row_ids, n, out, memkind);
+}
+
+// Reference shapes <-> padded slot layout.  Host staging; called rarely.
+int fnn_set_dense(fnn_handle* h, int layer, const float* W, const float* b, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (layer < 1 || layer > 3 || !W || !b) FAIL(h, FNN_ERR_ARG, "layer must be 1..3, W and b non-null");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int F = h->F, K = h->K, H1 = h->H1, H2 = h->H2, H1p = h->H1p, H2p = h->H2p;
+    const size_t nW = layer == 1 ? (size_t)h->xdim * H1 : layer == 2 ? (size_t)H1 * H2 : (size_t)H2;
+    const size_t nb = layer == 1 ? H1 : layer == 2 ? H2 : 1;
+    std::vector<float> hw(nW), hb(nb);
+    if (memkind == FNN_MEM_HOST) { memcpy(hw.data(), W, nW * 4); memcpy(hb.data(), b, nb * 4); }
+    else {
+        HIPCHK(h, hipMemcpy(hw.data(), W, nW * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(hb.data(), b, nb * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (layer == 1) {
+        std::vector<float> p(h->n1, 0.f);
+        for (int f = 0; f < F; ++f)
+            for (int l = 0; l < K; ++l)
+                memcpy(&p[(size_t)(f * SLOT + l) * H1p], &hw[(size_t)(1 + f * K + l) * H1], H1 * 4);
+        memcpy(&p[(size_t)K * H1p], &hw[0], H1 * 4);                 // w1[0,:] rides on the w_0 slot
+        memcpy(&p[(size_t)(SLOT + K) * H1p], hb.data(), H1 * 4);     // b1 rides on the ones slot
+        HIPCHK(h, hipMemcpy(h->master, p.data(), h->n1 * 4, hipMemcpyHostToDevice));
+    } else if (layer == 2) {
+        std::vector<float> p(h->n2, 0.f);
+        for (int i = 0; i < H1; ++i) memcpy(&p[(size_t)i * H2p], &hw[(size_t)i * H2], H2 * 4);
+        memcpy(&p[(size_t)H1 * H2p], hb.data(), H2 * 4);
+        HIPCHK(h, hipMemcpy(h->master + h->n1, p.data(), h->n2 * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> p(H2p, 0.f);
+        memcpy(p.data(), hw.data(), H2 * 4); p[H2] = hb[0];
+        HIPCHK(h, hipMemcpy(h->master + h->nw12, p.data(), (size_t)H2p * 4, hipMemcpyHostToDevice));
+    }
+    if (h->bf16) launch_update<bf16_t>(h, nullptr, 0.f); else launch_update<float>(h, nullptr, 0.f);
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    h->dense_set[layer - 1] = true;
+    return FNN_OK;
+}
+
+int fnn_get_dense(fnn_handle* h, int layer, float* W, float* b, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (layer < 1 || layer > 3 || !W || !b) FAIL(h, FNN_ERR_ARG, "layer must be 1..3, W and b non-null");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int F = h->F, K = h->K, H1 = h->H1, H2 = h->H2, H1p = h->H1p, H2p = h->H2p;
+    std::vector<float> m(h->nw);
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    HIPCHK(h, hipMemcpy(m.data(), h->master, h->nw * 4, hipMemcpyDeviceToHost));
+    const size_t nW = layer == 1 ? (size_t)h->xdim * H1 : layer == 2 ? (size_t)H1 * H2 : (size_t)H2;
+    const size_t nb = layer == 1 ? H1 : layer == 2 ? H2 : 1;
+    std::vector<float> hw(nW), hb(nb);
+    if (layer == 1) {
+        memcpy(&hw[0], &m[(size_t)K * H1p], H1 * 4);
+        for (int f = 0; f < F; ++f)
+            for (int l = 0; l < K; ++l)
+                memcpy(&hw[(size_t)(1 + f * K + l) * H1], &m[(size_t)(f * SLOT + l) * H1p], H1 * 4);
+        memcpy(hb.data(), &m[(size_t)(SLOT + K) * H1p], H1 * 4);
+    } else if (layer == 2) {
+        const float* p = &m[h->n1];
+        for (int i = 0; i < H1; ++i) memcpy(&hw[(size_t)i * H2], &p[(size_t)i * H2p], H2 * 4);
+        memcpy(hb.data(), &p[(size_t)H1 * H2p], H2 * 4);
+    } else {
+        memcpy(hw.data(), &m[h->nw12], H2 * 4); hb[0] = m[h->nw12 + H2];
+    }
+    if (memkind == FNN_MEM_HOST) { memcpy(W, hw.data(), nW * 4); memcpy(b, hb.data(), nb * 4); }
+    else {
+        HIPCHK(h, hipMemcpy(W, hw.data(), nW * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(b, hb.data(), nb * 4, hipMemcpyHostToDevice));
+    }
+    return FNN_OK;
+}
+
+int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (B <= 0 || B > h->Bmax) FAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
+    if (!h->table16) FAIL(h, FNN_ERR_STATE, "fnn_set_table has not been called");
+    if (!ids || !x_out) FAIL(h, FNN_ERR_ARG, "null pointer");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int32_t* ids_dev = ids; float* x_dev = x_out;
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(h->st_ids, ids, (size_t)B * h->F * 4, hipMemcpyHostToDevice, h->st));
+        ids_dev = h->st_ids; x_dev = h->st_x;
+    }
+    const size_t n = (size_t)B * h->xdim;
+    {
+        ProfScope ps(h, "gather_ref", h->st);
+        hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
+                           h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
+    }
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(x_out, x_dev, n * 4, hipMemcpyDeviceToHost, h->st));
+        return check_async(h);
+    }
+    return FNN_OK;
+}
+
+int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* mask1,
+                   const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind)
+{
+    int rc = check_ready(h, B);
+    if (rc != FNN_OK) return rc;
+    if (!ids || !y || !mask1 || !mask2) FAIL(h, FNN_ERR_ARG, "ids, y, mask1, mask2 must be non-null");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_begin called twice without fnn_step_end");
+    HIPCHK(h, hipSetDevice(h->dev));
+    if (b_size <= 0) b_size = B;
+    rc = update_cpow(h, b_size, B);
+    if (rc != FNN_OK) return rc;
+    const int32_t* ids_d = ids; const float* y_d = y; const uint8_t *m1 = mask1, *m2 = mask2;
+    float* p_d = p_out; float* gx_d = gx_out;
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(h->st_ids, ids, (size_t)B * h->F * 4, hipMemcpyHostToDevice, h->st));
+        HIPCHK(h, hipMemcpyAsync(h->st_y, y, (size_t)B * 4, hipMemcpyHostToDevice, h->st));
+        HIPCHK(h, hipMemcpyAsync(h->st_m1, mask1, (size_t)h->H1, hipMemcpyHostToDevice, h->st));
+        HIPCHK(h, hipMemcpyAsync(h->st_m2, mask2, (size_t)h->H2, hipMemcpyHostToDevice, h->st));
+        ids_d = h->st_ids; y_d = h->st_y; m1 = h->st_m1; m2 = h->st_m2;
+        if (p_out) p_d = h->st_p;
+        if (gx_out) gx_d = h->st_x;
+    }
+    rc = h->bf16 ? run_step<bf16_t>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d)
+                 : run_step<float>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d);
+    if (rc != FNN_OK) return rc;
+    if (memkind == FNN_MEM_HOST) {
+        if (p_out) HIPCHK(h, hipMemcpyAsync(p_out, p_d, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
+        if (gx_out) HIPCHK(h, hipMemcpyAsync(gx_out, gx_d, (size_t)B * h->xdim * 4, hipMemcpyDeviceToHost, h->st));
+        if (p_out || gx_out) HIPCHK(h, hipStreamSynchronize(h->st));
+    }
+    h->in_step = true; h->step_B = B;
+    return FNN_OK;
+}
+
+int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats)
+{
+    if (!h || !dev_ptr || !n_floats) return FNN_ERR_ARG;
+    *dev_ptr = h->bucket; *n_floats = (int64_t)h->nw;
+    return FNN_OK;
+}
+
+int fnn_step_end(fnn_handle* h, float* loss_sum_out)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_end without fnn_step_begin");
+    HIPCHK(h, hipSetDevice(h->dev));
+    {
+        ProfScope ps(h, "update", h->st);
+        if (h->bf16) launch_update<bf16_t>(h, h->bucket, h->cfg.lr); else launch_update<float>(h, h->bucket, h->cfg.lr);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->in_step = false;
+    if (loss_sum_out) return fnn_last_loss(h, loss_sum_out);
+    return FNN_OK;
+}
+
+int fnn_last_loss(fnn_handle* h, float* loss_sum_out)
+{
+    if (!h || !loss_sum_out) return FNN_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipMemcpyAsync(loss_sum_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToHost, h->st));
+    return check_async(h);
+}
+
+int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* mask1,
+                   const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind,
+                   float* loss_sum_out)
+{
+    int rc = fnn_step_begin(h, ids, y, B, mask1, mask2, b_size, p_out, gx_out, memkind);
+    if (rc != FNN_OK) return rc;
+    return fnn_step_end(h, loss_sum_out);
+}
+
+int fnn_predict(fnn_handle* h, const int32_t* ids, int B, float* p_out, int memkind)
+{
+    int rc = check_ready(h, B);
+    if (rc != FNN_OK) return rc;
+    if (!ids || !p_out) FAIL(h, FNN_ERR_ARG, "null pointer");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int32_t* ids_d = ids; float* p_d = p_out;
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(h->st_ids, ids, (size_t)B * h->F * 4, hipMemcpyHostToDevice, h->st));
+        ids_d = h->st_ids; p_d = h->st_p;
+    }
+    rc = h->bf16 ? run_step<bf16_t>(h, ids_d, nullptr, B, nullptr, nullptr, false, p_d, nullptr)
+                 : run_step<float>(h, ids_d, nullptr, B, nullptr, nullptr, false, p_d, nullptr);
+    if (rc != FNN_OK) return rc;
+    HIPCHK(h, hipGetLastError());
+    if (memkind == FNN_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(p_out, p_d, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
+        return check_async(h);
+    }
+    return FNN_OK;
+}
+
+int fnn_prof_enable(fnn_handle* h, int on) { if (!h) return FNN_ERR_ARG; h->prof = on != 0; return FNN_OK; }
+
+static int prof_collect(fnn_handle* h)
+{
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st_side));
+    for (auto& kv : h->prof_slots) {
+        for (auto& p : kv.second.ev) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { kv.second.ms += ms; kv.second.n += 1; }
+            hipEventDestroy(p.first); hipEventDestroy(p.second);
+        }
+        kv.second.ev.clear();
+    }
+    return FNN_OK;
+}
+
+int fnn_prof_reset(fnn_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    int rc = prof_collect(h);
+    h->prof_slots.clear();
+    return rc;
+}
+
+int fnn_prof_get(fnn_handle* h, const char* which, double* avg_ms, int64_t* launches)
+{
+    if (!h || !which || !avg_ms) return FNN_ERR_ARG;
+    int rc = prof_collect(h);
+    if (rc != FNN_OK) return rc;
+    auto it = h->prof_slots.find(which);
+    if (it == h->prof_slots.end() || it->second.n == 0) { *avg_ms = 0.0; if (launches) *launches = 0; return FNN_OK; }
+    *avg_ms = it->second.ms / (double)it->second.n;
+    if (launches) *launches = it->second.n;
+    return FNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,504 @@
+// fnn_kernels.hip.h -- device code of libfnn_hip.so (gfx950 / CDNA4 only).
+//
+// Data layout in HBM:
+//   table16  float [n_rows][16]   FM rows padded 44 B -> 64 B (one aligned line piece per row;
+//                                 slots >= K stay 0).  python/FNN_wnzh.py:76 feat_weights.
+//   x'       T [Ba][K1p]          layer-one array in "slot" layout: column 16*f + l holds
+//                                 row(ids[t][f])[l]; column K (a pad slot of field 0) holds w_0
+//                                 (the reference's x[0], python/FNN_wnzh.py:93) and column 16+K
+//                                 holds the constant 1 that turns b1 into a row of W1p.
+//   W1p      [K1p][H1p], W2p [H1p][H2p], w3p [H2p]: dense tensors padded the same way, the
+//                                 bias of each layer stored as the weight row of the "ones"
+//                                 column of its input (b1 = W1p[16+K], b2 = W2p[H1], b3 = w3p[H2]).
+//   Every activation is kept row-major [Ba][N] (A operand of the next GEMM) and transposed
+//   [N][ldT] (operands of the weight-gradient GEMMs, whose contraction runs over examples).
+//
+// All matrix products run on the matrix cores: v_mfma_f32_16x16x32_bf16 (FNN_PREC_BF16) or the
+// exact-f32 v_mfma_f32_16x16x4_f32 (FNN_PREC_F32, the parity mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fnn {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SLOT = 16;            // padded row width (floats) of the FM table
+constexpr int ACT_TANH = 0, ACT_SIGMOID = 1, ACT_LINEAR = 2;
+constexpr double FIX_SCALE = 17592186044416.0;  // 2^44: fixed-point scale of the scatter sums
+
+template <typename T> struct Traits;
+template <> struct Traits<float> {
+    typedef f32x4 frag;
+    static constexpr int EPL = 4;   // elements per lane per fragment (16 B)
+    static constexpr int KS = 16;   // k covered by one fragment pair
+};
+template <> struct Traits<bf16_t> {
+    typedef bf16x8 frag;
+    static constexpr int EPL = 8;
+    static constexpr int KS = 32;
+};
+
+// One fragment pair -> accumulate.  Operand maps (cdna_hip_programming.md section 3):
+//   16x16x32 bf16: lane l holds A[row l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][col l&15].
+//   16x16x4  f32 : lane l holds A[row l&15][k = l>>4],        B[k = l>>4][col l&15]; here each
+//   lane loads 4 consecutive k (k = 4*(l>>4) + m) and MFMA m consumes element m of both
+//   operands -- a permutation of k shared by A and B, so the sum over k is complete.
+__device__ inline void mma(f32x4& acc, const bf16x8 a, const bf16x8 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ inline void mma(f32x4& acc, const f32x4 a, const f32x4 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+__device__ inline void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ inline void store4(bf16_t* p, float a, float b, float c, float d) {
+    bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ inline float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline float4 load4(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+__device__ inline float act_fn(float z, int act) {
+    if (act == ACT_TANH) return tanhf(z);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-z));
+    return z;
+}
+// derivative of the activation written in terms of its (possibly masked) output d
+__device__ inline float dact_fn(float d, int act) {
+    if (act == ACT_TANH) return 1.0f - d * d;
+    if (act == ACT_SIGMOID) return d * (1.0f - d);
+    return 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// A3  embedding gather: ids [B][F] -> x' [Ba][K1p] and x'^T [K1p][ldT]
+//     (python/FNN_wnzh.py:87-96 feats_to_layer_one_array, batched as :224-237).
+// One thread = 4 consecutive examples x one field x one 16-byte quarter of the 64-B row, so the
+// four lanes of a row read one aligned 64-B piece and both output layouts get 4-element stores.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ ids, int B, int Ba, int F,
+                                                int K, const float* __restrict__ table16,
+                                                int64_t n_rows, float w0, T* __restrict__ xp, int K1p,
+                                                T* __restrict__ xpT, int ldT, int* __restrict__ err)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = gid & 3;
+    const int f = (gid >> 2) % F;
+    const int t0 = ((gid >> 2) / F) * 4;
+    if (t0 >= Ba) return;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + i;
+        int64_t id = -1;
+        if (t < B) {
+            id = ids[(size_t)t * F + f];
+            if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
+        }
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0) r = *reinterpret_cast<const float4*>(table16 + (size_t)id * SLOT + 4 * q);
+        v[i][0] = r.x; v[i][1] = r.y; v[i][2] = r.z; v[i][3] = r.w;
+        if (t < B && q == (K >> 2)) {
+            if (f == 0) v[i][K & 3] = w0;       // x[0] = w_0               (:93)
+            if (f == 1) v[i][K & 3] = 1.0f;     // ones column: b1 is a row of W1p
+        }
+    }
+    const int c0 = f * SLOT + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        store4(xp + (size_t)(t0 + i) * K1p + c0, v[i][0], v[i][1], v[i][2], v[i][3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        store4(xpT + (size_t)(c0 + j) * ldT + t0, v[0][j], v[1][j], v[2][j], v[3][j]);
+}
+
+// Reference-layout gather for fnn_gather(): x [B][1+F*K] float (python/FNN_wnzh.py:91-96).
+__global__ void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
+                             const float* __restrict__ table16, int64_t n_rows, float w0,
+                             float* __restrict__ x, int* __restrict__ err)
+{
+    const int xdim = 1 + F * K;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)B * xdim) return;
+    const int t = (int)(gid / xdim), i = (int)(gid % xdim);
+    float v = 0.f;
+    if (i == 0) v = w0;
+    else {
+        const int f = (i - 1) / K, l = (i - 1) % K;
+        int64_t id = ids[(size_t)t * F + f];
+        if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
+        if (id >= 0) v = table16[(size_t)id * SLOT + l];
+    }
+    x[gid] = v;
+}
+
+// gx' [B][K1p] (slot layout) -> gx [B][1+F*K] (what `train` returns, python/FNN_wnzh.py:179).
+__global__ void k_gx_ref(const float* __restrict__ gxp, int K1p, int B, int F, int K,
+                         float* __restrict__ gx)
+{
+    const int xdim = 1 + F * K;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)B * xdim) return;
+    const int t = (int)(gid / xdim), i = (int)(gid % xdim);
+    int c = K;                                   // d cost / d x[0] lives in the w_0 slot
+    if (i > 0) c = ((i - 1) / K) * SLOT + (i - 1) % K;
+    gx[gid] = gxp[(size_t)t * K1p + c];
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA GEMM  C[M][N] = A[M][K] * Bt[N][K]^T  with a fused epilogue.
+// One wave owns a 16 x (16*NT) output strip and streams its operands straight from L2 into
+// fragment registers (16 B per lane, k-contiguous in both operands; no LDS, no barriers).
+// grid = (M/64, N/(16*NT), splitK); block = 4 waves = 4 consecutive 16-row strips.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct EpiFwd {        // A4: act(z) * mask, ones column, both layouts
+    T* out; int ld; T* outT; int ldT; const uint8_t* mask; int act; int H; int B;
+    __device__ void operator()(int row0, int col, const f32x4& acc, int) const {
+        float m = 0.f;
+        if (col < H) m = mask ? (float)mask[col] : 1.0f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = (col < H) ? act_fn(acc[r], act) * m : (col == H ? 1.0f : 0.0f);
+            v[r] = (row0 + r < B) ? x : 0.0f;
+            out[(size_t)(row0 + r) * ld + col] = (T)v[r];
+        }
+        if (outT) store4(outT + (size_t)col * ldT + row0, v[0], v[1], v[2], v[3]);
+    }
+};
+template <typename T> struct EpiBwd {        // A5: delta = (delta_next * W^T) * mask * act'(d)
+    T* out; int ld; T* outT; int ldT; const T* d; const uint8_t* mask; int act; int H; int B;
+    __device__ void operator()(int row0, int col, const f32x4& acc, int) const {
+        float m = 0.f;
+        if (col < H) m = mask ? (float)mask[col] : 1.0f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dv = (float)d[(size_t)(row0 + r) * ld + col];
+            float x = acc[r] * m * dact_fn(dv, act);
+            v[r] = (row0 + r < B && col < H) ? x : 0.0f;
+            out[(size_t)(row0 + r) * ld + col] = (T)v[r];
+        }
+        store4(outT + (size_t)col * ldT + row0, v[0], v[1], v[2], v[3]);
+    }
+};
+struct EpiF32 {                               // plain float output (gx', split-K slabs)
+    float* out; int ld; size_t zstride;
+    __device__ void operator()(int row0, int col, const f32x4& acc, int z) const {
+        float* o = out + (size_t)z * zstride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(size_t)(row0 + r) * ld + col] = acc[r];
+    }
+};
+
+template <typename T, int NT, typename Epi>
+__global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
+                                              const T* __restrict__ Bt, int ldb, int klen, Epi epi)
+{
+    typedef typename Traits<T>::frag frag;
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    const int col0 = blockIdx.y * (16 * NT);
+    const size_t k0 = (size_t)blockIdx.z * klen + (lane >> 4) * EPL;
+    const T* ap = A + (size_t)(row0 + (lane & 15)) * lda + k0;
+    const T* bp = Bt + (size_t)(col0 + (lane & 15)) * ldb + k0;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int k = 0; k < klen; k += KS) {
+        const frag a = *reinterpret_cast<const frag*>(ap + k);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const frag b = *reinterpret_cast<const frag*>(bp + (size_t)n * 16 * ldb + k);
+            mma(acc[n], a, b);
+        }
+    }
+    // C/D map of the 16x16 shapes: col = lane & 15, row = 4*(lane >> 4) + reg.
+    const int r0 = row0 + 4 * (lane >> 4);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) epi(r0, col0 + n * 16 + (lane & 15), acc[n], blockIdx.z);
+}
+
+// ------------------------------------------------------------------------------------------
+// Output unit + loss + delta_2 (python/FNN_wnzh.py:169,172 and the first two lines of the
+// closed form in SURVEY 8a/A5):  z3 = d2.w3p (b3 rides on the ones column), p = sigmoid(z3),
+// xent, delta3 = p - y, delta2 = delta3 * w3 * r2 * (1 - d2^2); per-block partials of
+// gw3p = d2^T delta3 and of the loss.  16 lanes share 4 rows; a lane owns 4 columns of every
+// 64-column chunk.  block = 256 threads = 64 rows.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p, int H2,
+                                              const float* __restrict__ w3p,
+                                              const uint8_t* __restrict__ mask2,
+                                              const float* __restrict__ y, int B, int train,
+                                              float* __restrict__ p_out, T* __restrict__ dl2,
+                                              T* __restrict__ dl2T, int ldT,
+                                              float* __restrict__ gw3_part,
+                                              float* __restrict__ loss_part)
+{
+    __shared__ float s_gw3[4][256];      // per-wave column partials (H2p <= 256)
+    __shared__ float s_loss[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int row0 = blockIdx.x * 64 + wave * 16 + g * 4;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < H2p; cb += 64) {
+        const int c = cb + c16 * 4;
+        const float4 w = *reinterpret_cast<const float4*>(w3p + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 d = load4(d2 + (size_t)(row0 + r) * H2p + c);
+            z[r] += d.x * w.x + d.y * w.y + d.z * w.z + d.w * w.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        z[r] += __shfl_xor(z[r], 1); z[r] += __shfl_xor(z[r], 2);
+        z[r] += __shfl_xor(z[r], 4); z[r] += __shfl_xor(z[r], 8);
+    }
+    float d3[4], loss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = row0 + r;
+        const float p = 1.0f / (1.0f + expf(-z[r]));
+        d3[r] = 0.f;
+        if (t < B) {
+            if (p_out && c16 == 0) p_out[t] = p;
+            if (train) {
+                const float yy = y[t];
+                d3[r] = p - yy;
+                // -y log p - (1-y) log(1-p) = softplus(z) - y z
+                const float sp = fmaxf(z[r], 0.f) + log1pf(expf(-fabsf(z[r])));
+                if (c16 == 0) loss += sp - yy * z[r];
+            }
+        }
+    }
+    if (!train) return;
+    for (int cb = 0; cb < H2p; cb += 64) {
+        const int c = cb + c16 * 4;
+        const float4 w = *reinterpret_cast<const float4*>(w3p + c);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = (c + j < H2) ? (mask2 ? (float)mask2[c + j] : 1.f) : 0.f;
+        float o[4][4], gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 d = load4(d2 + (size_t)(row0 + r) * H2p + c);
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[r][j] = d3[r] * wv[j] * m[j] * (1.0f - dv[j] * dv[j]);   // layer 2 is tanh (:165)
+                gsum[j] += dv[j] * d3[r];
+            }
+            store4(dl2 + (size_t)(row0 + r) * H2p + c, o[r][0], o[r][1], o[r][2], o[r][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            store4(dl2T + (size_t)(c + j) * ldT + row0, o[0][j], o[1][j], o[2][j], o[3][j]);
+            float s = gsum[j];
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            if (g == 0) s_gw3[wave][c + j] = s;
+        }
+    }
+    loss += __shfl_xor(loss, 16); loss += __shfl_xor(loss, 32);
+    if (lane == 0) s_loss[wave] = loss;
+    __syncthreads();
+    for (int c = threadIdx.x; c < H2p; c += 256)
+        gw3_part[(size_t)blockIdx.x * H2p + c] = s_gw3[0][c] + s_gw3[1][c] + s_gw3[2][c] + s_gw3[3][c];
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense gradient bucket: sum the split-K slabs and the head partials in a fixed order, add the
+// L2 term 2*lambda1*theta (python/FNN_wnzh.py:173; SNN: all six tensors), and the loss sum.
+// ------------------------------------------------------------------------------------------
+__global__ void k_reduce(const float* __restrict__ slab, int splitk, size_t nw_all, size_t nw12,
+                         const float* __restrict__ gw3_part, int nblk, int H2p,
+                         const float* __restrict__ master, float lambda1, int reg_all,
+                         const float* __restrict__ loss_part, float* __restrict__ bucket,
+                         float* __restrict__ loss_sum)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += loss_part[b];
+        *loss_sum = s;
+    }
+    if (i >= nw_all) return;
+    float g = 0.f;
+    if (i < nw12) {
+        for (int z = 0; z < splitk; ++z) g += slab[(size_t)z * nw12 + i];
+        if (reg_all) g += 2.0f * lambda1 * master[i];
+    } else {
+        const int j = (int)(i - nw12);
+        for (int b = 0; b < nblk; ++b) g += gw3_part[(size_t)b * H2p + j];
+        g += 2.0f * lambda1 * master[i];
+    }
+    bucket[i] = g;
+}
+
+// theta <- theta - lr * g  (python/FNN_wnzh.py:179-182) on the f32 masters, then refresh the
+// compute-precision shadows in both orientations (forward wants W^T k-contiguous, backward W).
+template <typename T>
+__global__ void k_update(float* __restrict__ master, const float* __restrict__ bucket, float lr,
+                         int K1p, int H1p, int H2p, T* __restrict__ w1, T* __restrict__ w1t,
+                         T* __restrict__ w2, T* __restrict__ w2t)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n1 = (size_t)K1p * H1p, n2 = (size_t)H1p * H2p;
+    if (i >= n1 + n2 + H2p) return;
+    float w = master[i];
+    if (bucket) { w -= lr * bucket[i]; master[i] = w; }
+    if (i < n1) {
+        const int r = (int)(i / H1p), c = (int)(i % H1p);
+        w1[i] = (T)w; w1t[(size_t)c * K1p + r] = (T)w;
+    } else if (i < n1 + n2) {
+        const size_t j = i - n1;
+        const int r = (int)(j / H2p), c = (int)(j % H2p);
+        w2[j] = (T)w; w2t[(size_t)c * H1p + r] = (T)w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A6  sparse-row SGD with the reference's sequential duplicate semantics
+// (python/FNN_wnzh.py:299-306): a row hit by m examples (in example order) with slot gradients
+// g_1..g_m ends at  row*c^m - lr * sum_j g_j * c^(m-j),  c = 1 - 2*lambda_fm*lr/b_size.
+//   k_sort      per field: bitonic sort of (row, t) keys in LDS, then every sorted entry learns
+//               its segment [s, e) by binary search -> rec {row, t, s, e}.  Independent of the
+//               gradients, so it runs on a side stream under the MLP.
+//   k_scatter   every (entry, 16-B quarter) adds -lr*g*c^(e-1-pos) into the segment's
+//               accumulator in 2^-44 fixed point with integer atomics: integer addition is
+//               associative, so the result is bitwise reproducible whatever the arrival order.
+//   k_finalize  the segment head writes row*c^m + sum back (one f32 rounding per step) and
+//               clears the accumulator.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, int B, int F,
+                                               int64_t n_rows, int N2, int4* __restrict__ rec)
+{
+    extern __shared__ unsigned long long s_key[];
+    const int f = blockIdx.x;
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) {
+        unsigned long long key = ~0ull;
+        if (i < B) {
+            const int64_t id = ids[(size_t)i * F + f];
+            if (id >= 0 && id < n_rows) key = ((unsigned long long)id << 32) | (unsigned)i;
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= N2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < N2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int pos = threadIdx.x; pos < N2; pos += blockDim.x) {
+        const unsigned long long key = s_key[pos];
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (key != ~0ull) {
+            const unsigned long long lo_key = key & 0xffffffff00000000ull;
+            const unsigned long long hi_key = lo_key + 0x100000000ull;
+            int lo = 0, hi = pos;                     // first index with key >= lo_key
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_key[mid] < lo_key) lo = mid + 1; else hi = mid; }
+            const int s = lo;
+            lo = pos + 1; hi = N2;                    // first index with key >= hi_key
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_key[mid] < hi_key) lo = mid + 1; else hi = mid; }
+            r = make_int4((int)(key >> 32), (int)(key & 0xffffffffu), s, lo);
+        }
+        rec[(size_t)f * N2 + pos] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const int4* __restrict__ rec, int N2, int F, int K,
+                                                 const float* __restrict__ gxp, int K1p,
+                                                 const double* __restrict__ cpow, double lr,
+                                                 unsigned long long* __restrict__ accum)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(gid & 3);
+    const size_t e = gid >> 2;                         // f * N2 + pos
+    if (e >= (size_t)F * N2) return;
+    const int4 r = rec[e];
+    if (r.x < 0) return;
+    const int f = (int)(e / N2), pos = (int)(e % N2);
+    const float4 g = *reinterpret_cast<const float4*>(gxp + (size_t)r.y * K1p + f * SLOT + 4 * q);
+    const double cp = -lr * cpow[r.w - 1 - pos];
+    const float gv[4] = {g.x, g.y, g.z, g.w};
+    unsigned long long* a = accum + ((size_t)f * N2 + r.z) * SLOT + 4 * q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * q + j < K) {
+            const long long fx = __double2ll_rn((double)gv[j] * cp * FIX_SCALE);
+            atomicAdd(a + j, (unsigned long long)fx);
+        }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const int4* __restrict__ rec, int N2, int F, int K,
+                                                  const double* __restrict__ cpow,
+                                                  unsigned long long* __restrict__ accum,
+                                                  float* __restrict__ table16)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(gid & 3);
+    const size_t e = gid >> 2;
+    if (e >= (size_t)F * N2) return;
+    const int4 r = rec[e];
+    const int pos = (int)(e % N2);
+    if (r.x < 0 || pos != r.z) return;                 // only the head of a segment
+    const double cm = cpow[r.w - r.z];
+    unsigned long long* a = accum + e * SLOT + 4 * q;
+    float* row = table16 + (size_t)r.x * SLOT + 4 * q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * q + j < K) {
+            const double s = (double)(long long)a[j] * (1.0 / FIX_SCALE);
+            row[j] = (float)((double)row[j] * cm + s);
+            a[j] = 0ull;
+        }
+}
+
+// helpers for fnn_set_table / fnn_get_table / fnn_get_rows
+__global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int K,
+                             float* __restrict__ table16)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n_rows * SLOT) return;
+    const size_t r = gid / SLOT; const int l = (int)(gid % SLOT);
+    table16[gid] = (l < K) ? rows[r * K + l] : 0.f;
+}
+__global__ void k_unpack_rows(const float* __restrict__ table16, const int64_t* __restrict__ row_ids,
+                              int64_t n, int64_t n_rows, int K, float* __restrict__ out,
+                              int* __restrict__ err)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * K) return;
+    const size_t i = gid / K; const int l = (int)(gid % K);
+    int64_t r = row_ids ? row_ids[i] : (int64_t)i;
+    if (r < 0 || r >= n_rows) { atomicOr(err, 1); out[gid] = 0.f; return; }
+    out[gid] = table16[(size_t)r * SLOT + l];
+}
+
+}  // namespace fnn

@@ -1,0 +1,138 @@
+"""Loader interface #1: same class / method names as the reference's python/data_fm.py
+(`DataFM`, `feat_layer_one_index`, `feats_to_layer_one_array`, `get_batch_data`, `get_xy_fm`,
+`get_fxy_fm`), re-built around a dense row table so that the layer-one array `x` becomes a
+device-side product of the HIP gather instead of 16 dict lookups per example.
+
+Host logic only (text parsing, id mapping).  `get_batch_data` needs an attached FNNEngine for
+`x` (fnn_gather); the id fast path (`get_batch_ids`, `load_ids`) is what the training loop uses.
+"""
+import linecache
+
+import numpy
+
+
+class DataFM(object):
+    # python/data_fm.py:17-18
+    name_field = {'weekday': 0, 'hour': 1, 'useragent': 2, 'IP': 3, 'region': 4, 'city': 5,
+                  'adexchange': 6, 'domain': 7, 'slotid': 8, 'slotwidth': 9, 'slotheight': 10,
+                  'slotvisibility': 11, 'slotformat': 12, 'creative': 13, 'advertiser': 14,
+                  'slotprice': 15}
+
+    def __init__(self, fm_model_file, engine=None):
+        """Parses `fm.model.txt` (python/data_fm.py:15-44): line 1 `w_0 feat_num rank`, then
+        `feat w v_1..v_rank <fieldname>:<rest>`.  Unknown field name -> KeyError, as there."""
+        self.fm_model_file = fm_model_file
+        self.engine = engine
+        self.feat_field = {}
+        self.feat_weights = {}
+        self.feat_row = {}           # feat id -> row index of the dense table (file order)
+        self.w_0 = 0
+        self.k = 0
+        self.xdim = 0
+        rows, fields = [], []
+        with open(fm_model_file, 'r') as fi:
+            head = fi.readline().strip().split()
+            self.w_0 = float(head[0])
+            self.k = int(head[2]) + 1                          # w and v
+            self.xdim = 1 + len(self.name_field) * self.k
+            k = self.k
+            for line in fi:
+                s = line.strip().split()
+                if not s:
+                    continue
+                feat = int(s[0])
+                weights = [float(v) for v in s[1:1 + k]]
+                tag = s[1 + k]
+                field = self.name_field[tag[0:tag.index(':')]]
+                if feat in self.feat_row:                     # later line overwrites, as a dict does
+                    r = self.feat_row[feat]
+                    rows[r] = weights
+                    fields[r] = field
+                else:
+                    self.feat_row[feat] = len(rows)
+                    rows.append(weights)
+                    fields.append(field)
+                self.feat_weights[feat] = weights
+                self.feat_field[feat] = field
+        self.rows = numpy.asarray(rows, dtype=numpy.float64).reshape(len(rows), self.k)
+        self.field_of_row = numpy.asarray(fields, dtype=numpy.int32)
+
+    # ------------------------------------------------------------------ reference API
+    def feat_layer_one_index(self, feat, l):                  # python/data_fm.py:46-47
+        return 1 + self.feat_field[feat] * self.k + l
+
+    def feats_to_layer_one_array(self, feats):
+        """python/data_fm.py:49-54, single example, host utility (not the hot path: batches go
+        through fnn_gather).  Reads the parse-time weights, like the reference's class does."""
+        x = numpy.zeros(self.xdim)
+        x[0] = self.w_0
+        for feat in feats:
+            lo = self.feat_layer_one_index(feat, 0)
+            x[lo:lo + self.k] = self.feat_weights[feat]
+        return x
+
+    def get_xy_fm(self, line):                                # python/data_fm.py:72-77
+        feats, y = self._parse(line)
+        return self.feats_to_layer_one_array(feats), y
+
+    def get_fxy_fm(self, line):                               # python/data_fm.py:79-84
+        feats, y = self._parse(line)
+        return feats, self.feats_to_layer_one_array(feats), y
+
+    def get_batch_data(self, file, index, size):              # 1,5 -> lines 1,2,3,4,5
+        """python/data_fm.py:57-70: (farray list of feature-id lists, xarray [b,xdim] float32,
+        yarray [b] int32); blank lines skipped.  x is produced on the GPU by fnn_gather from the
+        engine's CURRENT table (the reference's script form re-reads its updated feat_weights too,
+        python/FNN_wnzh.py:95)."""
+        farray, ids, yarray = self.get_batch_ids(file, index, size)
+        if self.engine is None:
+            raise RuntimeError("DataFM.get_batch_data: attach an FNNEngine (engine=...): the layer-one "
+                               "array is a device-side product of fnn_gather; there is no CPU path")
+        if len(farray) == 0:
+            return farray, numpy.zeros((0, self.xdim), dtype=numpy.float32), yarray
+        xarray = self.engine.gather(ids).cpu().numpy()
+        return farray, xarray, yarray
+
+    # ------------------------------------------------------------------ id fast path
+    @staticmethod
+    def _parse(line):
+        s = line.replace(':', ' ').split()
+        return [int(s[j]) for j in range(1, len(s), 2)], int(s[0])
+
+    def feats_to_ids(self, feats):
+        """feature ids of one example -> int32 [16] row indices, slot = field, -1 = empty field;
+        a later feature of the same field overwrites an earlier one (python/data_fm.py:52-53).
+        Unknown feature -> KeyError (python/FNN_wnzh.py:95)."""
+        out = numpy.full(len(self.name_field), -1, dtype=numpy.int32)
+        for feat in feats:
+            out[self.feat_field[feat]] = self.feat_row[feat]
+        return out
+
+    def get_batch_ids(self, file, index, size):
+        farray, ids, ys = [], [], []
+        for i in range(index, index + size):
+            line = linecache.getline(file, i)
+            if line.strip() != '':
+                feats, y = self._parse(line.strip())
+                farray.append(feats)
+                ids.append(self.feats_to_ids(feats))
+                ys.append(y)
+        ids = numpy.asarray(ids, dtype=numpy.int32).reshape(len(ys), len(self.name_field))
+        return farray, ids, numpy.asarray(ys, dtype=numpy.int32)
+
+    def load_ids(self, file):
+        """Whole file -> (ids int32 [N,16], y int32 [N]); blank lines skipped."""
+        ids, ys = [], []
+        with open(file, 'r') as fi:
+            for line in fi:
+                if line.strip() == '':
+                    continue
+                feats, y = self._parse(line)
+                ids.append(self.feats_to_ids(feats))
+                ys.append(y)
+        return (numpy.asarray(ids, dtype=numpy.int32).reshape(len(ys), len(self.name_field)),
+                numpy.asarray(ys, dtype=numpy.int32))
+
+    def table(self):
+        """(rows float32 [D,K], field_of_row int32 [D], w_0) for FNNEngine.set_table."""
+        return self.rows.astype(numpy.float32), self.field_of_row, self.w_0

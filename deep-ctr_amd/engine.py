@@ -1,0 +1,242 @@
+"""FNNEngine: PyTorch-ROCm plumbing (device memory, streams) around the C ABI of libfnn_hip.so.
+
+The engine stands where the compiled Theano callables `train` / `predict` stand in the reference
+(python/FNN_wnzh.py:177-183) and where its Python gather / sparse-update loops stand
+(:87-96, :299-306).  All arithmetic happens in the HIP library; torch only owns buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class FNNError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "fnn_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_ACTS = {'tanh': _capi.FNN_ACT_TANH, 'sigmoid': _capi.FNN_ACT_SIGMOID, 'linear': _capi.FNN_ACT_LINEAR}
+
+
+class FNNEngine(object):
+    """One handle = one GPU + one HIP stream.
+
+    Parameters follow python/FNN_wnzh.py:18-49: hidden1, hidden2, lr, lambda1, lambda_fm, acti_type.
+    precision: 'f32' (parity mode) or 'bf16' (throughput mode).
+    """
+
+    def __init__(self, n_fields=16, k=11, hidden1=300, hidden2=100, max_batch=4096, precision='bf16',
+                 acti_type='tanh', lr=0.001, lambda1=0.0, lambda_fm=0.1, reg_all=False, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise FNNError(_capi.FNN_ERR_HIP, "no HIP device visible to PyTorch-ROCm; the FNN hot path has "
+                                              "no CPU fallback")
+        self._torch = torch
+        self.lib = _capi.load()
+        self.device = torch.device('cuda', device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.F, self.K, self.H1, self.H2 = n_fields, k, hidden1, hidden2
+        self.xdim = 1 + n_fields * k
+        self.max_batch = max_batch
+        self.precision = precision
+        cfg = _capi.fnn_cfg(n_fields, k, hidden1, hidden2, max_batch,
+                            _capi.FNN_PREC_BF16 if precision == 'bf16' else _capi.FNN_PREC_F32,
+                            _ACTS[acti_type], 1 if reg_all else 0, lr, lambda1, lambda_fm, device,
+                            C.c_void_p(self.stream.cuda_stream))
+        h = C.c_void_p()
+        rc = self.lib.fnn_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise FNNError(rc, (self.lib.fnn_last_error(None) or b'').decode())
+        self.h = h
+        self.n_rows = 0
+        self._bucket = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise FNNError(rc, (self.lib.fnn_last_error(self.h) or b'').decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.fnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev(self, a, dtype):
+        """numpy / torch -> contiguous torch tensor of `dtype` on this device."""
+        torch = self._torch
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def _enter(self):
+        self.stream.wait_stream(self._torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        self._torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def sync(self):
+        self._ck(self.lib.fnn_sync(self.h))
+
+    def set_hparams(self, lr, lambda1, lambda_fm):
+        self._ck(self.lib.fnn_set_hparams(self.h, lr, lambda1, lambda_fm))
+
+    # ------------------------------------------------------------------ state
+    def set_table(self, rows, field_of_row, w0):
+        """rows [D,K] float, field_of_row [D] int  (feat_weights / feat_field / w_0,
+        python/FNN_wnzh.py:62-84)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        fo = np.ascontiguousarray(field_of_row, dtype=np.int32)
+        assert rows.ndim == 2 and rows.shape[1] == self.K and fo.shape[0] == rows.shape[0]
+        self._ck(self.lib.fnn_set_table(self.h, rows.ctypes.data, rows.shape[0], fo.ctypes.data,
+                                        float(w0), _capi.FNN_MEM_HOST))
+        self.n_rows = rows.shape[0]
+
+    def get_table(self):
+        out = np.empty((self.n_rows, self.K), dtype=np.float32)
+        self._ck(self.lib.fnn_get_table(self.h, out.ctypes.data, _capi.FNN_MEM_HOST))
+        return out
+
+    def get_rows(self, row_ids):
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        out = np.empty((ids.shape[0], self.K), dtype=np.float32)
+        self._ck(self.lib.fnn_get_rows(self.h, ids.ctypes.data, ids.shape[0], out.ctypes.data,
+                                       _capi.FNN_MEM_HOST))
+        return out
+
+    def set_dense(self, p):
+        """p: dict w1 [xdim,H1], b1 [H1], w2 [H1,H2], b2 [H2], w3 [H2], b3 scalar."""
+        for layer, (wn, bn) in enumerate((('w1', 'b1'), ('w2', 'b2'), ('w3', 'b3')), start=1):
+            W = np.ascontiguousarray(p[wn], dtype=np.float32)
+            b = np.ascontiguousarray(np.atleast_1d(p[bn]), dtype=np.float32)
+            self._ck(self.lib.fnn_set_dense(self.h, layer, W.ctypes.data, b.ctypes.data, _capi.FNN_MEM_HOST))
+
+    def get_dense(self):
+        shapes = {1: ((self.xdim, self.H1), (self.H1,)), 2: ((self.H1, self.H2), (self.H2,)),
+                  3: ((self.H2,), (1,))}
+        out = {}
+        for layer, (ws, bs) in shapes.items():
+            W = np.empty(ws, dtype=np.float32)
+            b = np.empty(bs, dtype=np.float32)
+            self._ck(self.lib.fnn_get_dense(self.h, layer, W.ctypes.data, b.ctypes.data, _capi.FNN_MEM_HOST))
+            out['w%d' % layer] = W
+            out['b%d' % layer] = b if layer < 3 else float(b[0])
+        return out
+
+    # ------------------------------------------------------------------ hot path
+    def gather(self, ids):
+        """A3: ids [B,F] int32 (slot f = field f, -1 = empty) -> x [B,xdim] float32 tensor."""
+        torch = self._torch
+        ids_t = self._dev(ids, torch.int32)
+        B = ids_t.shape[0]
+        x = torch.empty((B, self.xdim), dtype=torch.float32, device=self.device)
+        self._enter()
+        self._ck(self.lib.fnn_gather(self.h, ids_t.data_ptr(), B, x.data_ptr(), _capi.FNN_MEM_DEVICE))
+        self._leave()
+        return x
+
+    def _step_args(self, ids, y, mask1, mask2):
+        torch = self._torch
+        return (self._dev(ids, torch.int32), self._dev(y, torch.float32),
+                self._dev(mask1, torch.uint8), self._dev(mask2, torch.uint8))
+
+    def train_step(self, ids, y, mask1, mask2, b_size=0, want_p=False, want_gx=False, want_loss=True):
+        """One pass of the hot loop body (python/FNN_wnzh.py:296-306).  Returns a dict with the
+        optional outputs: 'loss' (float, sum of xent), 'p' [B], 'gx' [B,xdim]."""
+        torch = self._torch
+        ids_t, y_t, m1, m2 = self._step_args(ids, y, mask1, mask2)
+        B = ids_t.shape[0]
+        assert m1.numel() == self.H1 and m2.numel() == self.H2 and y_t.numel() == B
+        p = torch.empty(B, dtype=torch.float32, device=self.device) if want_p else None
+        gx = torch.empty((B, self.xdim), dtype=torch.float32, device=self.device) if want_gx else None
+        loss = C.c_float(0.0)
+        self._enter()
+        self._ck(self.lib.fnn_train_step(
+            self.h, ids_t.data_ptr(), y_t.data_ptr(), B, m1.data_ptr(), m2.data_ptr(), int(b_size),
+            p.data_ptr() if want_p else None, gx.data_ptr() if want_gx else None, _capi.FNN_MEM_DEVICE,
+            C.byref(loss) if want_loss else None))
+        self._leave()
+        out = {}
+        if want_loss:
+            out['loss'] = float(loss.value)
+        if want_p:
+            out['p'] = p
+        if want_gx:
+            out['gx'] = gx
+        return out
+
+    def step_begin(self, ids, y, mask1, mask2, b_size=0):
+        """Data-parallel half step: everything but the dense SGD.  Returns the flat dense-gradient
+        bucket as a torch tensor aliasing the library's buffer (all-reduce it, then step_end())."""
+        ids_t, y_t, m1, m2 = self._step_args(ids, y, mask1, mask2)
+        B = ids_t.shape[0]
+        self._enter()
+        self._ck(self.lib.fnn_step_begin(self.h, ids_t.data_ptr(), y_t.data_ptr(), B, m1.data_ptr(),
+                                         m2.data_ptr(), int(b_size), None, None, _capi.FNN_MEM_DEVICE))
+        self._keep = (ids_t, y_t, m1, m2)
+        return self.grad_bucket()
+
+    def grad_bucket(self):
+        if self._bucket is None:
+            ptr, n = C.c_void_p(), C.c_int64()
+            self._ck(self.lib.fnn_dense_grad_bucket(self.h, C.byref(ptr), C.byref(n)))
+            self._bucket = _tensor_from_ptr(self._torch, ptr.value, n.value, self.device)
+        return self._bucket
+
+    def step_end(self, want_loss=False):
+        loss = C.c_float(0.0)
+        self._ck(self.lib.fnn_step_end(self.h, C.byref(loss) if want_loss else None))
+        self._leave()
+        return float(loss.value) if want_loss else None
+
+    def last_loss(self):
+        loss = C.c_float(0.0)
+        self._ck(self.lib.fnn_last_loss(self.h, C.byref(loss)))
+        return float(loss.value)
+
+    def predict(self, ids):
+        """A4': p [B] float32 tensor (python/FNN_wnzh.py:183)."""
+        torch = self._torch
+        ids_t = self._dev(ids, torch.int32)
+        n = ids_t.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._enter()
+        for lo in range(0, n, self.max_batch):
+            hi = min(n, lo + self.max_batch)
+            self._ck(self.lib.fnn_predict(self.h, ids_t[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr(),
+                                          _capi.FNN_MEM_DEVICE))
+        self._leave()
+        return out
+
+    # ------------------------------------------------------------------ profiling hook
+    def prof_enable(self, on=True):
+        self._ck(self.lib.fnn_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.lib.fnn_prof_reset(self.h))
+
+    def prof_get(self, which):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.lib.fnn_prof_get(self.h, which.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def _tensor_from_ptr(torch, ptr, n, device):
+    """Zero-copy float32 view of `n` floats of device memory owned by the library."""
+
+    class _Holder(object):
+        pass
+
+    hld = _Holder()
+    hld.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False),
+                                    'version': 2}
+    return torch.as_tensor(hld, device=device)

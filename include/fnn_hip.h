@@ -1,0 +1,143 @@
+/* fnn_hip.h -- C ABI of libfnn_hip.so, the MI355X (gfx950) FNN hot path.
+ *
+ * Drop-in boundary for the compiled Theano callables of Atomu2014/deep-ctr and
+ * the two Python loops either side of them (paths relative to the reference):
+ *
+ *   train   = theano.function([x, y], [gx, w1, w2, w3, b1, b2, b3], updates=SGD)
+ *                                                   python/FNN_wnzh.py:177-182
+ *   predict = theano.function([x], [p_1])           python/FNN_wnzh.py:183
+ *   gather  : feats_to_layer_one_array / get_batch_data
+ *                                                   python/FNN_wnzh.py:87-96,224-237
+ *                                                   python/data_fm.py:46-70
+ *   scatter : the sparse-row SGD loop               python/FNN_wnzh.py:299-306
+ *
+ * Plain C: pointers, sizes, ints.  No C++ or torch types cross this boundary.
+ * Every function returns 0 (FNN_OK) or a negative error class; the message is
+ * available from fnn_last_error().  A handle is bound to one device and one
+ * HIP stream; calls on one handle are not re-entrant; work is asynchronous on
+ * the stream except where a host output pointer forces a synchronisation.
+ *
+ * Buffers passed in are owned by the caller.  `memkind` says whether the
+ * pointers of that call are host (FNN_MEM_HOST) or device (FNN_MEM_DEVICE,
+ * e.g. torch.Tensor.data_ptr()) addresses.
+ *
+ * Layouts (row-major, contiguous): ids int32 [B, F] with slot f = field f and
+ * -1 = no feature in that field; y float32 [B]; masks uint8 [H1], [H2];
+ * x / gx float32 [B, 1 + F*K] in the reference's layer-one layout
+ * (x[0] = w_0, x[1 + f*K + l] = row(ids[f])[l],  python/FNN_wnzh.py:87-96).
+ */
+#ifndef FNN_HIP_H
+#define FNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNN_OK          0
+#define FNN_ERR_ARG    -1   /* bad argument / unsupported shape              */
+#define FNN_ERR_HIP    -2   /* HIP runtime error (message has the HIP text)  */
+#define FNN_ERR_STATE  -3   /* call order (table or weights not set, ...)    */
+#define FNN_ERR_RANGE  -4   /* an id was outside [-1, n_rows)  (the reference
+                               raises KeyError, python/FNN_wnzh.py:95)       */
+#define FNN_ERR_NOMEM  -5
+
+#define FNN_PREC_F32    0   /* exact-f32 MFMA; the parity mode               */
+#define FNN_PREC_BF16   1   /* bf16 MFMA inputs, f32 accumulate, f32 masters */
+
+#define FNN_ACT_TANH    0   /* acti_type, python/FNN_wnzh.py:23,148-163      */
+#define FNN_ACT_SIGMOID 1
+#define FNN_ACT_LINEAR  2
+
+#define FNN_MEM_HOST    0
+#define FNN_MEM_DEVICE  1
+
+typedef struct fnn_cfg {
+    int32_t n_fields;     /* F: 16 for iPinYou (python/FNN_wnzh.py:51-53)     */
+    int32_t k;            /* K = rank + 1: row = [w, v_1..v_rank]  (:76)      */
+    int32_t hidden1;      /* python/FNN_wnzh.py:21,46                         */
+    int32_t hidden2;      /* python/FNN_wnzh.py:22,47                         */
+    int32_t max_batch;    /* largest B of any call; sizes the workspaces      */
+    int32_t precision;    /* FNN_PREC_*                                       */
+    int32_t act;          /* FNN_ACT_* for h1 (and h2 in predict); the second
+                             dropout layer is tanh regardless (:165)          */
+    int32_t reg_all;      /* 0: lambda1 on w3,b3 only (python/FNN_wnzh.py:173)
+                             1: on all six tensors (python/SNN_RBM.py:141)    */
+    float   lr;           /* python/FNN_wnzh.py:19,44                         */
+    float   lambda1;      /* :20,48                                           */
+    float   lambda_fm;    /* :49                                              */
+    int32_t device;       /* HIP device ordinal                               */
+    void*   stream;       /* hipStream_t to run on, or NULL = create one      */
+} fnn_cfg;
+
+typedef struct fnn_handle fnn_handle;
+
+const char* fnn_version(void);
+/* Message of the last failing call on `h` (or of the last failing fnn_create
+ * when h == NULL).  Valid until the next call on that handle. */
+const char* fnn_last_error(const fnn_handle* h);
+
+int fnn_create(const fnn_cfg* cfg, fnn_handle** out);
+int fnn_destroy(fnn_handle* h);
+int fnn_set_hparams(fnn_handle* h, float lr, float lambda1, float lambda_fm);
+void* fnn_stream(fnn_handle* h);               /* the hipStream_t in use      */
+int fnn_sync(fnn_handle* h);                   /* wait + report async errors
+                                                  (FNN_ERR_RANGE lands here)  */
+
+/* FM table = feat_weights / feat_field / w_0 of python/FNN_wnzh.py:62-84.
+ * rows [n_rows, K] float32, field_of_row [n_rows] int32 in [0, F). */
+int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows,
+                  const int32_t* field_of_row, float w0, int memkind);
+int fnn_get_table(fnn_handle* h, float* rows_out, int memkind);
+int fnn_get_rows(fnn_handle* h, const int64_t* row_ids, int64_t n, float* out, int memkind);
+
+/* Dense tensors, reference shapes (python/FNN_wnzh.py:106-140):
+ * layer 1: W [1+F*K, H1], b [H1];  layer 2: W [H1, H2], b [H2];
+ * layer 3: W [H2], b [1]. */
+int fnn_set_dense(fnn_handle* h, int layer, const float* W, const float* b, int memkind);
+int fnn_get_dense(fnn_handle* h, int layer, float* W, float* b, int memkind);
+
+/* A3: x_out [B, 1+F*K] = layer-one array of every example. */
+int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memkind);
+
+/* One pass of the hot loop body (python/FNN_wnzh.py:296-306):
+ * gather -> train(x, y) with the given dropout rows -> dense SGD -> sparse-row
+ * SGD with decay 1 - 2*lambda_fm*lr/b_size.  b_size <= 0 means B (the data-
+ * parallel caller passes the GLOBAL batch length).  Outputs are optional:
+ * p_out [B] = p_drop, gx_out [B, 1+F*K] (what `train` returns first),
+ * loss_sum_out = sum of the cross-entropy over the batch (HOST pointer; non-NULL
+ * forces a stream synchronisation). */
+int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B,
+                   const uint8_t* mask1, const uint8_t* mask2, int b_size,
+                   float* p_out, float* gx_out, int memkind, float* loss_sum_out);
+
+/* The same pass split for data parallelism: _begin runs everything except the
+ * dense SGD and leaves the dense gradients (sum over this rank's examples, the
+ * reference loss being a batch SUM, python/FNN_wnzh.py:173) in one flat f32
+ * bucket; the caller all-reduces the bucket (RCCL) on fnn_stream(); _end applies
+ * theta <- theta - lr * bucket. */
+int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B,
+                   const uint8_t* mask1, const uint8_t* mask2, int b_size,
+                   float* p_out, float* gx_out, int memkind);
+int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats);
+int fnn_step_end(fnn_handle* h, float* loss_sum_out);
+/* Sum of the cross-entropy of the last step on this rank (synchronises). */
+int fnn_last_loss(fnn_handle* h, float* loss_sum_out);
+
+/* A4': p_out [B] = predict(x) -- no masks, no rescale (python/FNN_wnzh.py:183). */
+int fnn_predict(fnn_handle* h, const int32_t* ids, int B, float* p_out, int memkind);
+
+/* Timing hook for bench.py: average device time (ms) of the kernel named
+ * `which` ("gather", "fwd1", "fwd2", "head", "bwd1", "gx", "wgrad", "reduce",
+ * "update", "sort", "scatter", "finalize") over the steps since the last
+ * fnn_prof_reset(); HIP events on the handle's own streams.  Profiling is off
+ * (zero overhead) until fnn_prof_enable(h, 1). */
+int fnn_prof_enable(fnn_handle* h, int on);
+int fnn_prof_reset(fnn_handle* h);
+int fnn_prof_get(fnn_handle* h, const char* which, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNN_HIP_H */

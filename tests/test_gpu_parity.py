@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libfnn_hip.so), against the float64
+oracle on the same seeded inputs, against the committed golden fixtures, and through
+size-independent properties at the full BASELINE shape.
+
+Tolerances (north_star: logloss/AUC within 1e-4 absolute of the CPU reference):
+  gather                exact (a copy)
+  f32 mode, one step    p_drop rtol 1e-4, gx rtol 2e-3 (+atol 1e-6), rows rtol 1e-5 / atol 2e-7
+  bf16 mode, one step   p_drop atol 2e-2, gx within 5e-2 of the gx scale (bf16 has 8 mantissa bits)
+  epochs on the demo    |d logloss| <= 1e-4, |d AUC| <= 1e-4 in f32 mode
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fnn_oracle as orc
+
+import deep_ctr_amd  # noqa: F401
+from deep_ctr_amd import _capi, synth
+from deep_ctr_amd.engine import FNNEngine, FNNError
+
+pytestmark = pytest.mark.gpu
+
+F, K, H1, H2 = 16, 11, 300, 100
+XDIM = 1 + F * K
+
+
+def f32r(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def make_problem(B, n_rows=1000, seed=0, h1=H1, h2=H2, dup_col=None, empty=()):
+    sizes = synth.field_sizes_tiny(n_rows) if n_rows < 100000 else synth.field_sizes_ipinyou(n_rows)
+    rows = synth.fm_table(sum(sizes), K, 0.05, seed)
+    fo = synth.field_of_row(sizes)
+    ids = synth.zipf_ids(B, sizes, 1.1, seed + 1)
+    if dup_col is not None:
+        ids[:, dup_col] = ids[0, dup_col]
+    for (t, f) in empty:
+        ids[t, f] = -1
+    rng = np.random.RandomState(seed + 2)
+    y = (rng.uniform(size=B) < 0.2).astype(np.float32)
+    p = orc.init_fnn_weights(XDIM, h1, h2, 'tanh', seed=1234)
+    p['w3'] = rng.uniform(-0.1, 0.1, h2)
+    p['b1'] = rng.uniform(-0.1, 0.1, h1)
+    p['b2'] = rng.uniform(-0.1, 0.1, h2)
+    p['b3'] = 0.05
+    p = {k: (f32r(v) if isinstance(v, np.ndarray) else float(np.float32(v))) for k, v in p.items()}
+    r1 = (rng.uniform(size=h1) < 0.5).astype(np.uint8)
+    r2 = (rng.uniform(size=h2) < 0.5).astype(np.uint8)
+    return rows, fo, ids, y, p, r1, r2
+
+
+def make_engine(rows, fo, p, w0=-3.0, prec='f32', max_batch=4096, lr=0.001, lam1=0.0, lamfm=0.1, h1=H1,
+                h2=H2, acti='tanh'):
+    eng = FNNEngine(F, K, h1, h2, max_batch=max_batch, precision=prec, acti_type=acti, lr=lr, lambda1=lam1,
+                    lambda_fm=lamfm)
+    eng.set_table(rows, fo, w0)
+    eng.set_dense(p)
+    return eng
+
+
+def test_library_reports_version(built):
+    lib = _capi.load()
+    assert b"gfx950" in lib.fnn_version()
+
+
+@pytest.mark.parametrize("B", [1, 7, 100, 1000])
+def test_gather_exact(built, B):
+    rows, fo, ids, y, p, r1, r2 = make_problem(B, empty=[(0, 3)])
+    eng = make_engine(rows, fo, p)
+    x = eng.gather(ids).cpu().numpy()
+    ref = orc.gather(rows.astype(np.float64), ids, -3.0).astype(np.float32)
+    assert np.array_equal(x, ref)
+    eng.close()
+
+
+def test_set_get_roundtrip(built):
+    rows, fo, ids, y, p, r1, r2 = make_problem(10)
+    eng = make_engine(rows, fo, p)
+    assert np.array_equal(eng.get_table(), rows)
+    assert np.array_equal(eng.get_rows([3, 999, 0]), rows[[3, 999, 0]])
+    d = eng.get_dense()
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+        assert np.array_equal(d[k], p[k].astype(np.float32)), k
+    assert d['b3'] == np.float32(p['b3'])
+    eng.close()
+
+
+def _check_step(eng, rows, ids, y, p, r1, r2, lr, lam1, lamfm, w0=-3.0, b_size=0, tol=1.0, acti='tanh'):
+    rows64 = rows.astype(np.float64).copy()
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    out = eng.train_step(ids, y, r1, r2, b_size=b_size, want_p=True, want_gx=True)
+    x = orc.gather(rows64, ids, w0)
+    gx, pre, loss, p_drop, g = orc.train_call(p64, x, y.astype(np.float64), r1.astype(np.float64),
+                                              r2.astype(np.float64), lr, lam1, acti)
+    orc.scatter_sgd(rows64, ids, gx, lr, lamfm, b_size if b_size > 0 else None)
+    np.testing.assert_allclose(out['p'].cpu().numpy(), p_drop, rtol=1e-4 * tol, atol=1e-6 * tol)
+    gscale = np.abs(gx).max()
+    np.testing.assert_allclose(out['gx'].cpu().numpy(), gx, rtol=2e-3 * tol, atol=2e-5 * gscale * tol + 1e-9)
+    assert abs(out['loss'] - loss) <= 2e-5 * tol * max(1.0, abs(loss))
+    np.testing.assert_allclose(eng.get_table(), rows64, rtol=1e-5 * tol, atol=2e-7 * tol)
+    d = eng.get_dense()
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+        gs = lr * np.abs(g[k]).max()
+        np.testing.assert_allclose(d[k], p64[k], rtol=1e-5 * tol, atol=1e-3 * gs * tol + 1e-7, err_msg=k)
+    assert abs(d['b3'] - p64['b3']) <= 1e-5 * tol
+    return rows64, p64
+
+
+@pytest.mark.parametrize("B,kw", [
+    (1, {}), (5, {"empty": [(2, 3), (4, 0)]}), (64, {"dup_col": 6}), (100, {}), (257, {"dup_col": 0}),
+    (1000, {"empty": [(0, 15)]}),
+])
+def test_train_step_f32_vs_oracle(built, B, kw):
+    rows, fo, ids, y, p, r1, r2 = make_problem(B, seed=B, **kw)
+    eng = make_engine(rows, fo, p, lr=0.01, lam1=0.02, lamfm=0.1)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.02, 0.1)
+    eng.close()
+
+
+def test_train_step_f32_global_batch_decay(built):
+    """Data-parallel callers pass the GLOBAL batch length for the decay constant (:304)."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(50, seed=3)
+    eng = make_engine(rows, fo, p, lr=0.05, lamfm=0.3)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.05, 0.0, 0.3, b_size=400)
+    eng.close()
+
+
+@pytest.mark.parametrize("acti", ['sigmoid', 'linear'])
+def test_other_activations(built, acti):
+    rows, fo, ids, y, p, r1, r2 = make_problem(40, seed=11)
+    eng = make_engine(rows, fo, p, lr=0.01, acti=acti)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.0, 0.1, acti=acti)
+    pr = eng.predict(ids).cpu().numpy()
+    d = {k: (f32r(v) if isinstance(v, np.ndarray) else v) for k, v in eng.get_dense().items()}
+    ref = orc.predict(d, orc.gather(eng.get_table().astype(np.float64), ids, -3.0), acti)
+    np.testing.assert_allclose(pr, ref, rtol=1e-4, atol=1e-6)
+    eng.close()
+
+
+def test_small_hidden_sizes(built):
+    rows, fo, ids, y, p, r1, r2 = make_problem(33, seed=5, h1=20, h2=9)
+    eng = make_engine(rows, fo, p, lr=0.01, h1=20, h2=9)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.0, 0.1)
+    eng.close()
+
+
+def test_multi_step_sequence_f32(built):
+    """Several consecutive steps: state carried on the device must track the oracle."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(600, seed=21)
+    eng = make_engine(rows, fo, p, lr=0.002)
+    rows64 = rows.astype(np.float64)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ms = orc.TheanoMaskStream(H1, H2, 0.5)
+    for j in range(6):
+        sl = slice(j * 100, (j + 1) * 100)
+        m1, m2 = ms.next()
+        out = eng.train_step(ids[sl], y[sl], m1.astype(np.uint8), m2.astype(np.uint8))
+        ref = orc.train_step(p64, rows64, -3.0, ids[sl], y[sl].astype(np.float64), m1, m2, 0.002, 0.0, 0.1)
+        assert abs(out['loss'] - ref['loss']) <= 1e-4 * abs(ref['loss'])
+    np.testing.assert_allclose(eng.get_table(), rows64, rtol=1e-4, atol=1e-6)
+    pr = eng.predict(ids).cpu().numpy()
+    np.testing.assert_allclose(pr, orc.predict(p64, orc.gather(rows64, ids, -3.0)), rtol=2e-4, atol=1e-6)
+    eng.close()
+
+
+def test_golden_step(built, golden_dir):
+    from deep_ctr_amd.data_fm import DataFM
+    g = np.load(os.path.join(golden_dir, 'step.npz'))
+    data = DataFM(os.path.join(golden_dir, 'demo', 'fm.model.txt'))
+    rows, fo, w0 = data.table()
+    p = orc.init_fnn_weights(XDIM, H1, H2, 'tanh', seed=1234)
+    p['w3'] = g['w3']; p['b3'] = float(g['b3'])
+    eng = make_engine(rows, fo, p, w0=w0, lr=float(g['lr']), lam1=float(g['lambda1']), lamfm=float(g['lambda_fm']))
+    assert np.array_equal(eng.gather(g['ids']).cpu().numpy(), g['x'].astype(np.float32))
+    out = eng.train_step(g['ids'], g['y'], g['r1'], g['r2'], want_p=True, want_gx=True)
+    np.testing.assert_allclose(out['p'].cpu().numpy(), g['p_drop'], rtol=1e-4)
+    np.testing.assert_allclose(out['gx'].cpu().numpy(), g['gx'], rtol=2e-3, atol=2e-5 * np.abs(g['gx']).max())
+    assert abs(out['loss'] - float(g['loss'])) <= 2e-5 * float(g['loss'])
+    np.testing.assert_allclose(eng.get_rows(g['touched']), g['rows_after'], rtol=1e-5, atol=2e-7)
+    d = eng.get_dense()
+    np.testing.assert_allclose(d['w3'], g['w3_after'], rtol=1e-5, atol=1e-7)
+    assert abs(d['w1'].astype(np.float64).sum() - float(g['w1_after_sum'])) < 1e-2
+    eng.close()
+
+
+def _run_demo_epochs(golden_dir, prec, epochs=3):
+    from deep_ctr_amd.data_fm import DataFM
+    from deep_ctr_amd import dl_utils as ut
+    from sklearn.metrics import log_loss, roc_auc_score
+    demo = os.path.join(golden_dir, 'demo')
+    data = DataFM(os.path.join(demo, 'fm.model.txt'))
+    rows, fo, w0 = data.table()
+    ut.seed_global(1234)
+    p = ut.init_fnn_weights(XDIM, H1, H2, 'tanh')
+    eng = make_engine(rows, fo, p, w0=w0, prec=prec, lr=0.001, lam1=0.0, lamfm=0.1)
+    tr_ids, tr_y = data.load_ids(os.path.join(demo, 'train.fm.txt'))
+    te_ids, te_y = data.load_ids(os.path.join(demo, 'test.fm.txt'))
+    srng = ut.RandomStreams(234)
+    srng.binomial(size=(1, XDIM), n=1, p=1)
+    r1 = srng.binomial(size=(1, H1), n=1, p=0.5)
+    r2 = srng.binomial(size=(1, H2), n=1, p=0.5)
+    hist = []
+    for ep in range(epochs):
+        for j in range(len(tr_y) // 100):
+            sl = slice(j * 100, (j + 1) * 100)
+            eng.train_step(tr_ids[sl], tr_y[sl], r1.draw()[0], r2.draw()[0], want_loss=False)
+        ptr = eng.predict(tr_ids).cpu().numpy().astype(np.float64)
+        pte = eng.predict(te_ids).cpu().numpy().astype(np.float64)
+        hist.append((roc_auc_score(tr_y, ptr), log_loss(tr_y, ptr), roc_auc_score(te_y, pte), log_loss(te_y, pte)))
+    eng.close()
+    return np.array(hist)
+
+
+def test_demo_epochs_f32_logloss_auc_within_1e4(built, golden_dir):
+    """BASELINE config 1 / north_star: logloss and AUC on the demo set within 1e-4 absolute of the
+    float64 restatement (same init, masks, order), 3 epochs, reference defaults."""
+    g = np.load(os.path.join(golden_dir, 'epoch.npz'))
+    h = _run_demo_epochs(golden_dir, 'f32')
+    assert np.abs(h[:, 0] - g['train_auc']).max() <= 1e-4
+    assert np.abs(h[:, 1] - g['train_logloss']).max() <= 1e-4
+    assert np.abs(h[:, 2] - g['test_auc']).max() <= 1e-4
+    assert np.abs(h[:, 3] - g['test_logloss']).max() <= 1e-4
+
+
+def test_demo_epochs_bf16_tracks_oracle(built, golden_dir):
+    """bf16 throughput mode: same run; logloss within 5e-3, AUC within 2e-2 (stated, not 1e-4)."""
+    g = np.load(os.path.join(golden_dir, 'epoch.npz'))
+    h = _run_demo_epochs(golden_dir, 'bf16')
+    print("bf16 demo deltas: logloss %.2e auc %.2e" % (np.abs(h[:, 3] - g['test_logloss']).max(),
+                                                      np.abs(h[:, 2] - g['test_auc']).max()))
+    assert np.abs(h[:, 1] - g['train_logloss']).max() <= 5e-3
+    assert np.abs(h[:, 3] - g['test_logloss']).max() <= 5e-3
+    assert np.abs(h[:, 2] - g['test_auc']).max() <= 2e-2
+
+
+def test_train_step_bf16_vs_oracle(built):
+    rows, fo, ids, y, p, r1, r2 = make_problem(512, seed=9, dup_col=12)
+    eng = make_engine(rows, fo, p, prec='bf16', lr=0.01)
+    out = eng.train_step(ids, y, r1, r2, want_p=True, want_gx=True)
+    rows64 = rows.astype(np.float64)
+    ref = orc.train_step(p, rows64, -3.0, ids, y.astype(np.float64), r1.astype(float), r2.astype(float),
+                         0.01, 0.0, 0.1)
+    assert np.abs(out['p'].cpu().numpy() - ref['p_drop']).max() < 2e-2
+    gs = np.abs(ref['gx']).max()
+    assert np.abs(out['gx'].cpu().numpy() - ref['gx']).max() < 5e-2 * gs
+    assert abs(out['loss'] - ref['loss']) < 2e-2 * ref['loss']
+    assert np.abs(eng.get_table() - rows64).max() < 5e-2 * 0.01 * gs + 1e-6
+    eng.close()
+
+
+def test_out_of_range_id_is_an_error(built):
+    rows, fo, ids, y, p, r1, r2 = make_problem(8)
+    eng = make_engine(rows, fo, p)
+    bad = ids.copy(); bad[3, 2] = rows.shape[0] + 5
+    with pytest.raises(FNNError) as ei:
+        eng.train_step(bad, y, r1, r2)
+    assert ei.value.code == _capi.FNN_ERR_RANGE
+    eng.train_step(ids, y, r1, r2)              # the handle stays usable
+    with pytest.raises(FNNError):
+        eng.train_step(np.zeros((5000, F), np.int32), np.zeros(5000, np.float32), r1, r2)   # B > max_batch
+    eng.close()
+
+
+def test_calls_before_setup_fail_loudly(built):
+    eng = FNNEngine(F, K, H1, H2, max_batch=64, precision='f32')
+    with pytest.raises(FNNError) as ei:
+        eng.predict(np.zeros((4, F), np.int32))
+    assert ei.value.code == _capi.FNN_ERR_STATE
+    eng.close()
+
+
+# ----------------------------------------------------------------- full BASELINE shape (config 2)
+@pytest.fixture(scope="module")
+def full_problem():
+    B = 4096
+    return make_problem(B, n_rows=synth.IPINYOU_DIMS, seed=1234)
+
+
+def test_full_shape_step_f32_vs_oracle(built, full_problem):
+    """16 fields, 937,670 one-hot dims, k=10, batch 4096: one f32 step against the oracle."""
+    rows, fo, ids, y, p, r1, r2 = full_problem
+    eng = make_engine(rows, fo, p, lr=0.001)
+    out = eng.train_step(ids, y, r1, r2, want_p=True, want_gx=True)
+    rows64 = rows.astype(np.float64)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ref = orc.train_step(p64, rows64, -3.0, ids, y.astype(np.float64), r1.astype(float), r2.astype(float),
+                         0.001, 0.0, 0.1)
+    np.testing.assert_allclose(out['p'].cpu().numpy(), ref['p_drop'], rtol=1e-4, atol=1e-6)
+    gs = np.abs(ref['gx']).max()
+    np.testing.assert_allclose(out['gx'].cpu().numpy(), ref['gx'], rtol=2e-3, atol=2e-5 * gs)
+    touched = np.unique(ids)
+    np.testing.assert_allclose(eng.get_rows(touched), rows64[touched], rtol=1e-5, atol=2e-7)
+    assert abs(out['loss'] - ref['loss']) <= 2e-5 * ref['loss']
+    eng.close()
+
+
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+def test_full_shape_properties(built, full_problem, prec):
+    """Size-independent properties at the full shape:
+    (1) untouched rows are bit-identical after a step (decay only on touched rows, :299-306);
+    (2) the dense gradient of a batch equals the sum of the gradients of its two halves (the loss
+        is a SUM, python/FNN_wnzh.py:173) -- the identity data parallelism relies on;
+    (3) two identical runs are bitwise reproducible (integer-atomic scatter, fixed-order reductions).
+    """
+    rows, fo, ids, y, p, r1, r2 = full_problem
+    B = ids.shape[0]
+
+    def run(sel):
+        eng = make_engine(rows, fo, p, prec=prec, lr=0.001)
+        bucket = eng.step_begin(ids[sel], y[sel], r1, r2, b_size=B).clone()
+        eng.step_end()
+        eng.sync()
+        tab = eng.get_table()
+        eng.close()
+        return bucket.cpu().numpy().astype(np.float64), tab
+
+    g_all, tab_all = run(slice(0, B))
+    g_a, _ = run(slice(0, B // 2))
+    g_b, _ = run(slice(B // 2, B))
+    scale = np.abs(g_all).max()
+    tol = 1e-5 if prec == 'f32' else 1e-5      # products are identical per example in both modes
+    assert np.abs(g_all - (g_a + g_b)).max() <= tol * scale
+    mask = np.ones(rows.shape[0], bool); mask[np.unique(ids)] = False
+    assert np.array_equal(tab_all[mask], rows[mask])
+    g_again, tab_again = run(slice(0, B))
+    assert np.array_equal(g_all, g_again) and np.array_equal(tab_all, tab_again)
