@@ -63,6 +63,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7).  Import torch
+    # FIRST so that the dynamic loader resolves libfnn_hip.so's libamdhip64.so.7 to that already
+    # loaded runtime; the other order maps two HIP/HSA runtimes into one process and the second
+    # one finds no device.  (A plain C host links against /opt/rocm as usual.)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libfnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
