@@ -246,7 +246,8 @@ def test_train_step_bf16_vs_oracle(built):
     gs = np.abs(ref['gx']).max()
     assert np.abs(out['gx'].cpu().numpy() - ref['gx']).max() < 5e-2 * gs
     assert abs(out['loss'] - ref['loss']) < 2e-2 * ref['loss']
-    assert np.abs(eng.get_table() - rows64).max() < 5e-2 * 0.01 * gs + 1e-6
+    upd = np.abs(rows64 - rows.astype(np.float64)).max()          # largest row update of the step
+    assert np.abs(eng.get_table() - rows64).max() < 5e-2 * upd + 1e-6
     eng.close()
 
 
@@ -309,12 +310,13 @@ def test_full_shape_properties(built, full_problem, prec):
 
     def run(sel):
         eng = make_engine(rows, fo, p, prec=prec, lr=0.001)
-        bucket = eng.step_begin(ids[sel], y[sel], r1, r2, b_size=B).clone()
-        eng.step_end()
+        bucket = eng.step_begin(ids[sel], y[sel], r1, r2, b_size=B)
+        eng.step_end()                      # leaves the bucket untouched
         eng.sync()
+        g = bucket.cpu().numpy().astype(np.float64)
         tab = eng.get_table()
         eng.close()
-        return bucket.cpu().numpy().astype(np.float64), tab
+        return g, tab
 
     g_all, tab_all = run(slice(0, B))
     g_a, _ = run(slice(0, B // 2))
