@@ -48,10 +48,12 @@ struct fnn_handle {
     // activations (T) and f32 work buffers
     void *xp = nullptr, *xpT = nullptr, *d1 = nullptr, *d1T = nullptr, *d2 = nullptr, *dl2 = nullptr,
          *dl2T = nullptr, *dl1 = nullptr, *dl1T = nullptr;
-    float *gxp = nullptr, *p_buf = nullptr, *gw3_part = nullptr, *loss_part = nullptr, *loss_dev = nullptr;
-    int nblk_head_max = 0;
+    float *gxp = nullptr, *p_buf = nullptr, *loss_t = nullptr, *loss_dev = nullptr;
+    void *d2T = nullptr, *dl3T = nullptr;
+    size_t nslab = 0;
     // scatter
-    int4* rec = nullptr; unsigned long long* accum = nullptr; double* cpow_dev = nullptr;
+    int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr;
+    double* cpow_dev = nullptr;
     std::vector<double> cpow_host; double cpow_c = -1.0; int cpow_n = 0;
     int* err_flag = nullptr;
     // host-pointer staging
@@ -144,15 +146,22 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     const int F = h->F, K = h->K, K1p = h->K1p, H1p = h->H1p, H2p = h->H2p, ldT = h->ldT;
     T *xp = (T*)h->xp, *xpT = (T*)h->xpT, *d1 = (T*)h->d1, *d1T = (T*)h->d1T, *d2 = (T*)h->d2,
       *dl2 = (T*)h->dl2, *dl2T = (T*)h->dl2T, *dl1 = (T*)h->dl1, *dl1T = (T*)h->dl1T;
-    int N2 = 64; while (N2 < B) N2 <<= 1;
+    int N2 = 256; while (N2 < B) N2 <<= 1;
+    T *d2T = (T*)h->d2T, *dl3T = (T*)h->dl3T;
 
     if (train) {   // A6 part 1: the sort only needs the ids; run it beside the MLP
         HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
         HIPCHK(h, hipStreamWaitEvent(h->st_side, h->ev_fork, 0));
         {
             ProfScope ps(h, "sort", h->st_side);
-            hipLaunchKernelGGL(k_sort, dim3(F), dim3(1024), (size_t)N2 * 8, h->st_side, ids, B, F,
-                               h->n_rows, N2, h->rec);
+            const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
+            const dim3 blk(N2 / kpt);
+            if (kpt == 4)
+                hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
+            else if (kpt == 8)
+                hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
+            else
+                hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
         }
         HIPCHK(h, hipEventRecord(h->ev_join, h->st_side));
     }
@@ -169,14 +178,14 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     }
     {   // A4 layer 2: d2 = tanh(d1 W2p) * r2   (predict: acti_type, no mask)
         ProfScope ps(h, "fwd2", h->st);
-        EpiFwd<T> e{d2, H2p, nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
+        EpiFwd<T> e{d2, H2p, train ? d2T : nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
         launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, H1p, Ba, H2p, H1p, 1, e);
     }
     {   // output unit, loss, delta2
         ProfScope ps(h, "head", h->st);
         hipLaunchKernelGGL((k_head<T>), dim3(Ba / 64), dim3(256), 0, h->st, d2, H2p, h->H2,
-                           h->master + h->nw12, m2, y, B, train ? 1 : 0, p_out, dl2, dl2T, ldT,
-                           h->gw3_part, h->loss_part);
+                           h->master + h->nw12, m2, y, B, train ? 1 : 0, p_out, dl2, dl2T, ldT, dl3T,
+                           h->loss_t);
     }
     if (!train) return FNN_OK;
     {   // A5: delta1 = (delta2 W2p^T) * r1 * act'(d1)
@@ -192,16 +201,18 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     {   // A5: dense gradients, contraction over the examples, split-K slabs
         ProfScope ps(h, "wgrad", h->st);
         const int klen = Ba / h->splitk;
-        EpiF32 e1{h->slab, H1p, h->nw12};
+        EpiF32 e1{h->slab, H1p, h->nslab};
         launch_gemm<T, 4>(h->st, xpT, ldT, dl1T, ldT, K1p, H1p, klen, h->splitk, e1);
-        EpiF32 e2{h->slab + h->n1, H2p, h->nw12};
+        EpiF32 e2{h->slab + h->n1, H2p, h->nslab};
         launch_gemm<T, 4>(h->st, d1T, ldT, dl2T, ldT, H1p, H2p, klen, h->splitk, e2);
+        EpiF32 e3{h->slab + h->nw12, 16, h->nslab};       // gw3p = d2^T delta3 (column 0)
+        launch_gemm<T, 1>(h->st, d2T, ldT, dl3T, ldT, H2p, 16, klen, h->splitk, e3);
     }
     {
         ProfScope ps(h, "reduce", h->st);
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((h->nw + 255) / 256)), dim3(256), 0, h->st, h->slab,
-                           h->splitk, h->nw, h->nw12, h->gw3_part, Ba / 64, H2p, h->master,
-                           h->cfg.lambda1, h->cfg.reg_all, h->loss_part, h->bucket, h->loss_dev);
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((h->nw + 255) / 256 + 1)), dim3(256), 0, h->st, h->slab,
+                           h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
+                           h->loss_t, Ba, h->bucket, h->loss_dev);
     }
     if (gx_out_dev) {
         const size_t n = (size_t)B * h->xdim;
@@ -210,16 +221,17 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     }
     // A6 part 2
     HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));
-    const size_t nthr = (size_t)F * N2 * 4;
     {
         ProfScope ps(h, "scatter", h->st);
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec, N2,
-                           F, K, h->gxp, K1p, h->cpow_dev, (double)h->cfg.lr, h->accum);
+        const size_t nthr = (size_t)F * N2;                 // 16 lanes per chunk of 16 entries
+        hipLaunchKernelGGL(k_scat1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec, N2, F, K,
+                           h->gxp, K1p, h->cpow_dev, (double)h->cfg.lr, h->table16, h->part, h->owner_cnt,
+                           h->owners);
     }
     {
         ProfScope ps(h, "finalize", h->st);
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec,
-                           N2, F, K, h->cpow_dev, h->accum, h->table16);
+        hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, h->owner_cnt, h->owners, N2, K, h->part,
+                           h->cpow_dev, (double)h->cfg.lr, h->table16);
     }
     HIPCHK(h, hipGetLastError());
     return FNN_OK;
@@ -274,14 +286,15 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->xdim = 1 + h->F * h->K;
     h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
-    h->N2max = 64; while (h->N2max < h->Bmax) h->N2max <<= 1;
+    h->N2max = 256; while (h->N2max < h->Bmax) h->N2max <<= 1;
     h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
     h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
     h->bf16 = cfg->precision == FNN_PREC_BF16;
     const size_t ts = tsize(h), Ba = h->ldT;
     CK(alloc_dev(h, &h->master, h->nw));
     CK(alloc_dev(h, &h->bucket, h->nw));
-    CK(alloc_dev(h, &h->slab, (size_t)h->splitk * h->nw12));
+    h->nslab = h->nw12 + (size_t)h->H2p * 16;
+    CK(alloc_dev(h, &h->slab, (size_t)h->splitk * h->nslab));
     CK(alloc_dev(h, (char**)&h->w1, h->n1 * ts));   CK(alloc_dev(h, (char**)&h->w1t, h->n1 * ts));
     CK(alloc_dev(h, (char**)&h->w2, h->n2 * ts));   CK(alloc_dev(h, (char**)&h->w2t, h->n2 * ts));
     CK(alloc_dev(h, (char**)&h->xp, Ba * h->K1p * ts));  CK(alloc_dev(h, (char**)&h->xpT, Ba * h->K1p * ts));
@@ -291,12 +304,14 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, (char**)&h->dl2, Ba * h->H2p * ts)); CK(alloc_dev(h, (char**)&h->dl2T, Ba * h->H2p * ts));
     CK(alloc_dev(h, &h->gxp, Ba * h->K1p));
     CK(alloc_dev(h, &h->p_buf, Ba));
-    h->nblk_head_max = (int)(Ba / 64);
-    CK(alloc_dev(h, &h->gw3_part, (size_t)h->nblk_head_max * h->H2p));
-    CK(alloc_dev(h, &h->loss_part, (size_t)h->nblk_head_max));
+    CK(alloc_dev(h, (char**)&h->d2T, Ba * h->H2p * ts));
+    CK(alloc_dev(h, (char**)&h->dl3T, Ba * 16 * ts));
+    CK(alloc_dev(h, &h->loss_t, Ba));
     CK(alloc_dev(h, &h->loss_dev, (size_t)1));
     CK(alloc_dev(h, &h->rec, (size_t)h->F * h->N2max));
-    CK(alloc_dev(h, &h->accum, (size_t)h->F * h->N2max * SLOT));
+    CK(alloc_dev(h, &h->part, (size_t)h->F * (h->N2max / 16) * 2 * SLOT));
+    CK(alloc_dev(h, &h->owners, (size_t)h->F * (h->N2max / 16)));
+    CK(alloc_dev(h, &h->owner_cnt, (size_t)1));
     CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
     CK(alloc_dev(h, &h->err_flag, (size_t)1));
     CK(alloc_dev(h, &h->st_ids, (size_t)h->Bmax * h->F));
@@ -304,8 +319,10 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, &h->st_m1, (size_t)h->H1p)); CK(alloc_dev(h, &h->st_m2, (size_t)h->H2p));
     CK(alloc_dev(h, &h->st_p, (size_t)h->Bmax));
     CK(alloc_dev(h, &h->st_x, (size_t)h->Bmax * h->xdim));
-    if ((size_t)h->N2max * 8 > 48 * 1024)
-        HK(hipFuncSetAttribute((const void*)k_sort, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
+    if (h->N2max == 8192)
+        HK(hipFuncSetAttribute((const void*)k_sort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
+    if (h->N2max == 16384)
+        HK(hipFuncSetAttribute((const void*)k_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
     HK(hipStreamSynchronize(h->st));
 #undef CK
 #undef HK
@@ -322,7 +339,7 @@ int fnn_destroy(fnn_handle* h)
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
-                    h->gw3_part, h->loss_part, h->loss_dev, h->rec, h->accum, h->cpow_dev, h->err_flag,
+                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->rec, h->part, h->owners, h->owner_cnt, h->cpow_dev, h->err_flag,
                     h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);

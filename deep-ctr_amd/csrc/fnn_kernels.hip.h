@@ -237,9 +237,10 @@ __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
 // ------------------------------------------------------------------------------------------
 // Output unit + loss + delta_2 (python/FNN_wnzh.py:169,172 and the first two lines of the
 // closed form in SURVEY 8a/A5):  z3 = d2.w3p (b3 rides on the ones column), p = sigmoid(z3),
-// xent, delta3 = p - y, delta2 = delta3 * w3 * r2 * (1 - d2^2); per-block partials of
-// gw3p = d2^T delta3 and of the loss.  16 lanes share 4 rows; a lane owns 4 columns of every
-// 64-column chunk.  block = 256 threads = 64 rows.
+// xent, delta3 = p - y, delta2 = delta3 * w3 * r2 * (1 - d2^2).  delta3 is also written as row 0
+// of a [16][ldT] matrix so that gw3p = d2^T delta3 is one more MFMA product of the weight-
+// gradient launch; the per-example loss goes to loss_t.  16 lanes share 4 rows; a lane owns 4
+// columns of every 64-column chunk.  block = 256 threads = 64 rows.
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p, int H2,
@@ -247,12 +248,9 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
                                               const uint8_t* __restrict__ mask2,
                                               const float* __restrict__ y, int B, int train,
                                               float* __restrict__ p_out, T* __restrict__ dl2,
-                                              T* __restrict__ dl2T, int ldT,
-                                              float* __restrict__ gw3_part,
-                                              float* __restrict__ loss_part)
+                                              T* __restrict__ dl2T, int ldT, T* __restrict__ dl3T,
+                                              float* __restrict__ loss_t)
 {
-    __shared__ float s_gw3[4][256];      // per-wave column partials (H2p <= 256)
-    __shared__ float s_loss[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
     const int row0 = blockIdx.x * 64 + wave * 16 + g * 4;
@@ -271,24 +269,27 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
         z[r] += __shfl_xor(z[r], 1); z[r] += __shfl_xor(z[r], 2);
         z[r] += __shfl_xor(z[r], 4); z[r] += __shfl_xor(z[r], 8);
     }
-    float d3[4], loss = 0.f;
+    float d3[4], ls[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int t = row0 + r;
         const float p = 1.0f / (1.0f + expf(-z[r]));
-        d3[r] = 0.f;
+        d3[r] = 0.f; ls[r] = 0.f;
         if (t < B) {
             if (p_out && c16 == 0) p_out[t] = p;
             if (train) {
                 const float yy = y[t];
                 d3[r] = p - yy;
                 // -y log p - (1-y) log(1-p) = softplus(z) - y z
-                const float sp = fmaxf(z[r], 0.f) + log1pf(expf(-fabsf(z[r])));
-                if (c16 == 0) loss += sp - yy * z[r];
+                ls[r] = fmaxf(z[r], 0.f) + log1pf(expf(-fabsf(z[r]))) - yy * z[r];
             }
         }
     }
     if (!train) return;
+    if (c16 == 0) {
+        store4(dl3T + row0, d3[0], d3[1], d3[2], d3[3]);
+        store4(loss_t + row0, ls[0], ls[1], ls[2], ls[3]);
+    }
     for (int cb = 0; cb < H2p; cb += 64) {
         const int c = cb + c16 * 4;
         const float4 w = *reinterpret_cast<const float4*>(w3p + c);
@@ -296,60 +297,53 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
         float m[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = (c + j < H2) ? (mask2 ? (float)mask2[c + j] : 1.f) : 0.f;
-        float o[4][4], gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        float o[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float4 d = load4(d2 + (size_t)(row0 + r) * H2p + c);
             const float dv[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
                 o[r][j] = d3[r] * wv[j] * m[j] * (1.0f - dv[j] * dv[j]);   // layer 2 is tanh (:165)
-                gsum[j] += dv[j] * d3[r];
-            }
             store4(dl2 + (size_t)(row0 + r) * H2p + c, o[r][0], o[r][1], o[r][2], o[r][3]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
             store4(dl2T + (size_t)(c + j) * ldT + row0, o[0][j], o[1][j], o[2][j], o[3][j]);
-            float s = gsum[j];
-            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-            if (g == 0) s_gw3[wave][c + j] = s;
-        }
     }
-    loss += __shfl_xor(loss, 16); loss += __shfl_xor(loss, 32);
-    if (lane == 0) s_loss[wave] = loss;
-    __syncthreads();
-    for (int c = threadIdx.x; c < H2p; c += 256)
-        gw3_part[(size_t)blockIdx.x * H2p + c] = s_gw3[0][c] + s_gw3[1][c] + s_gw3[2][c] + s_gw3[3][c];
-    if (threadIdx.x == 0) loss_part[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
 }
 
 // ------------------------------------------------------------------------------------------
-// Dense gradient bucket: sum the split-K slabs and the head partials in a fixed order, add the
-// L2 term 2*lambda1*theta (python/FNN_wnzh.py:173; SNN: all six tensors), and the loss sum.
+// Dense gradient bucket: sum the split-K slabs in a fixed order, add the L2 term 2*lambda1*theta
+// (python/FNN_wnzh.py:173; SNN: all six tensors); the last block sums the per-example losses.
+// Slab z = [W1p grads n1 | W2p grads n2 | gw3p as column 0 of an [H2p][16] tile].
 // ------------------------------------------------------------------------------------------
-__global__ void k_reduce(const float* __restrict__ slab, int splitk, size_t nw_all, size_t nw12,
-                         const float* __restrict__ gw3_part, int nblk, int H2p,
-                         const float* __restrict__ master, float lambda1, int reg_all,
-                         const float* __restrict__ loss_part, float* __restrict__ bucket,
-                         float* __restrict__ loss_sum)
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, int splitk,
+                                                size_t nw_all, size_t nw12, size_t nslab,
+                                                const float* __restrict__ master, float lambda1,
+                                                int reg_all, const float* __restrict__ loss_t, int Ba,
+                                                float* __restrict__ bucket, float* __restrict__ loss_sum)
 {
+    if (blockIdx.x == gridDim.x - 1) {                       // loss: fixed-shape tree
+        __shared__ float s_l[256];
+        float v = 0.f;
+        for (int i = threadIdx.x; i < Ba; i += 256) v += loss_t[i];
+        s_l[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s_l[threadIdx.x] += s_l[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *loss_sum = s_l[0];
+        return;
+    }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += loss_part[b];
-        *loss_sum = s;
-    }
     if (i >= nw_all) return;
+    const size_t src = (i < nw12) ? i : nw12 + (i - nw12) * 16;
     float g = 0.f;
-    if (i < nw12) {
-        for (int z = 0; z < splitk; ++z) g += slab[(size_t)z * nw12 + i];
-        if (reg_all) g += 2.0f * lambda1 * master[i];
-    } else {
-        const int j = (int)(i - nw12);
-        for (int b = 0; b < nblk; ++b) g += gw3_part[(size_t)b * H2p + j];
-        g += 2.0f * lambda1 * master[i];
-    }
+#pragma unroll 8
+    for (int z = 0; z < splitk; ++z) g += slab[(size_t)z * nslab + src];
+    if (reg_all || i >= nw12) g += 2.0f * lambda1 * master[i];
     bucket[i] = g;
 }
 
@@ -379,105 +373,178 @@ __global__ void k_update(float* __restrict__ master, const float* __restrict__ b
 // A6  sparse-row SGD with the reference's sequential duplicate semantics
 // (python/FNN_wnzh.py:299-306): a row hit by m examples (in example order) with slot gradients
 // g_1..g_m ends at  row*c^m - lr * sum_j g_j * c^(m-j),  c = 1 - 2*lambda_fm*lr/b_size.
-//   k_sort      per field: bitonic sort of (row, t) keys in LDS, then every sorted entry learns
-//               its segment [s, e) by binary search -> rec {row, t, s, e}.  Independent of the
-//               gradients, so it runs on a side stream under the MLP.
-//   k_scatter   every (entry, 16-B quarter) adds -lr*g*c^(e-1-pos) into the segment's
-//               accumulator in 2^-44 fixed point with integer atomics: integer addition is
-//               associative, so the result is bitwise reproducible whatever the arrival order.
-//   k_finalize  the segment head writes row*c^m + sum back (one f32 rounding per step) and
-//               clears the accumulator.
+//   k_sort    per field: bitonic sort of the (row, t) keys -- in registers for strides inside a
+//             thread, with wave shuffles inside a wave, through LDS only for the few strides that
+//             cross waves -- then every sorted entry learns its segment [s, e) by binary search
+//             -> rec {row, t, s, e}.  Independent of the gradients: runs on a side stream under
+//             the MLP.
+//   k_scat1   a 16-lane group (lane = slot of the row) owns 16 consecutive sorted entries and adds
+//             g * c^(e-1-pos) in f64 per run of equal rows.  The weight is absolute inside the
+//             segment, so partial sums of a segment cut by chunk borders simply add up.  Runs
+//             that lie inside the chunk are written back at once; the others leave a partial and
+//             the run that opens a multi-chunk segment registers its owner.
+//   k_scat2   one workgroup per registered owner adds the partials of its segment in a fixed
+//             order and writes the row.  No float atomics anywhere: the result is bitwise
+//             reproducible.
 // ------------------------------------------------------------------------------------------
+template <int KPT>
 __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, int B, int F,
-                                               int64_t n_rows, int N2, int4* __restrict__ rec)
+                                               int64_t n_rows, int N2, int4* __restrict__ rec,
+                                               int* __restrict__ owner_cnt)
 {
     extern __shared__ unsigned long long s_key[];
-    const int f = blockIdx.x;
-    for (int i = threadIdx.x; i < N2; i += blockDim.x) {
-        unsigned long long key = ~0ull;
+    const int f = blockIdx.x, tid = threadIdx.x;       // blockDim.x == N2 / KPT
+    if (f == 0 && tid == 0) *owner_cnt = 0;
+    unsigned long long key[KPT];
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) {
+        const int i = tid * KPT + a;
+        unsigned long long kk = ~0ull;
         if (i < B) {
             const int64_t id = ids[(size_t)i * F + f];
-            if (id >= 0 && id < n_rows) key = ((unsigned long long)id << 32) | (unsigned)i;
+            if (id >= 0 && id < n_rows) kk = ((unsigned long long)id << 32) | (unsigned)i;
         }
-        s_key[i] = key;
+        key[a] = kk;
     }
-    __syncthreads();
     for (int k = 2; k <= N2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < N2; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s_key[i], b = s_key[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+            if (j < KPT) {                              // both elements live in this thread
+#pragma unroll
+                for (int jj = KPT >> 1; jj > 0; jj >>= 1) {
+                    if (j == jj) {
+#pragma unroll
+                        for (int a = 0; a < KPT; ++a) {
+                            const int b = a ^ jj;
+                            if (b > a) {
+                                const bool up = ((tid * KPT + a) & k) == 0;
+                                const unsigned long long x = key[a], y = key[b];
+                                if ((x > y) == up) { key[a] = y; key[b] = x; }
+                            }
+                        }
+                    }
+                }
+            } else if (j < 64 * KPT) {                  // partner lane of the same wave
+                const int d = j / KPT;
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) {
+                    const int i = tid * KPT + a;
+                    const unsigned long long other = __shfl_xor(key[a], d);
+                    const bool keepmin = ((i & j) == 0) == ((i & k) == 0);
+                    const unsigned long long mine = key[a];
+                    key[a] = keepmin ? (mine < other ? mine : other) : (mine > other ? mine : other);
+                }
+            } else {                                    // partner in another wave: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) s_key[tid * KPT + a] = key[a];
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < KPT; ++a) {
+                    const int i = tid * KPT + a;
+                    const unsigned long long other = s_key[i ^ j];
+                    const bool keepmin = ((i & j) == 0) == ((i & k) == 0);
+                    const unsigned long long mine = key[a];
+                    key[a] = keepmin ? (mine < other ? mine : other) : (mine > other ? mine : other);
                 }
             }
-            __syncthreads();
         }
     }
-    for (int pos = threadIdx.x; pos < N2; pos += blockDim.x) {
-        const unsigned long long key = s_key[pos];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) s_key[tid * KPT + a] = key[a];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < KPT; ++a) {
+        const int pos = tid * KPT + a;
+        const unsigned long long kk = key[a];
         int4 r = make_int4(-1, 0, 0, 0);
-        if (key != ~0ull) {
-            const unsigned long long lo_key = key & 0xffffffff00000000ull;
+        if (kk != ~0ull) {
+            const unsigned long long lo_key = kk & 0xffffffff00000000ull;
             const unsigned long long hi_key = lo_key + 0x100000000ull;
             int lo = 0, hi = pos;                     // first index with key >= lo_key
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_key[mid] < lo_key) lo = mid + 1; else hi = mid; }
             const int s = lo;
             lo = pos + 1; hi = N2;                    // first index with key >= hi_key
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_key[mid] < hi_key) lo = mid + 1; else hi = mid; }
-            r = make_int4((int)(key >> 32), (int)(key & 0xffffffffu), s, lo);
+            r = make_int4((int)(kk >> 32), (int)(kk & 0xffffffffu), s, lo);
         }
         rec[(size_t)f * N2 + pos] = r;
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter(const int4* __restrict__ rec, int N2, int F, int K,
-                                                 const float* __restrict__ gxp, int K1p,
-                                                 const double* __restrict__ cpow, double lr,
-                                                 unsigned long long* __restrict__ accum)
+__global__ __launch_bounds__(256) void k_scat1(const int4* __restrict__ rec, int N2, int F, int K,
+                                               const float* __restrict__ gxp, int K1p,
+                                               const double* __restrict__ cpow, double lr,
+                                               float* __restrict__ table16, double* __restrict__ part,
+                                               int* __restrict__ owner_cnt, int4* __restrict__ owners)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = (int)(gid & 3);
-    const size_t e = gid >> 2;                         // f * N2 + pos
-    if (e >= (size_t)F * N2) return;
-    const int4 r = rec[e];
-    if (r.x < 0) return;
-    const int f = (int)(e / N2), pos = (int)(e % N2);
-    const float4 g = *reinterpret_cast<const float4*>(gxp + (size_t)r.y * K1p + f * SLOT + 4 * q);
-    const double cp = -lr * cpow[r.w - 1 - pos];
-    const float gv[4] = {g.x, g.y, g.z, g.w};
-    unsigned long long* a = accum + ((size_t)f * N2 + r.z) * SLOT + 4 * q;
+    const int l = threadIdx.x & 15;                       // slot of the row
+    const int G = (blockIdx.x * 256 + threadIdx.x) >> 4;  // chunk of 16 sorted entries
+    const int NQ = N2 >> 4;
+    if (G >= F * NQ) return;
+    const int f = G / NQ, q = G % NQ, base = q * 16;
+    const int4 mine = rec[(size_t)f * N2 + base + l];
+    const double wmine = (mine.x >= 0) ? cpow[mine.w - 1 - (base + l)] : 0.0;
+    int row[16], sg[16], eg[16];
+    float g[16], wold[16];
+    double w[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (4 * q + j < K) {
-            const long long fx = __double2ll_rn((double)gv[j] * cp * FIX_SCALE);
-            atomicAdd(a + j, (unsigned long long)fx);
+    for (int j = 0; j < 16; ++j) {
+        row[j] = __shfl(mine.x, j, 16);
+        const int t = __shfl(mine.y, j, 16);
+        sg[j] = __shfl(mine.z, j, 16);
+        eg[j] = __shfl(mine.w, j, 16);
+        w[j] = __shfl(wmine, j, 16);
+        const bool live = row[j] >= 0 && l < K;
+        g[j] = live ? gxp[(size_t)t * K1p + f * SLOT + l] : 0.f;
+        wold[j] = live ? table16[(size_t)row[j] * SLOT + l] : 0.f;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (row[j] < 0) continue;
+        acc += (double)g[j] * w[j];
+        const bool last = (j == 15) || (row[j + 1 < 16 ? j + 1 : 15] != row[j]);
+        if (!last) continue;
+        const int s = sg[j], e = eg[j];
+        if (s >= base && e <= base + 16) {                 // the whole segment lies in this chunk
+            if (l < K) table16[(size_t)row[j] * SLOT + l] = (float)((double)wold[j] * cpow[e - s] - lr * acc);
+        } else {
+            const int which = (s < base) ? 0 : 1;          // 0: enters from the left; 1: opens here
+            part[(((size_t)f * NQ + q) * 2 + which) * SLOT + l] = acc;
+            if (which == 1 && l == 0) owners[atomicAdd(owner_cnt, 1)] = make_int4(f, s, e, row[j]);
         }
+        acc = 0.0;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const int4* __restrict__ rec, int N2, int F, int K,
-                                                  const double* __restrict__ cpow,
-                                                  unsigned long long* __restrict__ accum,
-                                                  float* __restrict__ table16)
+__global__ __launch_bounds__(256) void k_scat2(const int* __restrict__ owner_cnt,
+                                               const int4* __restrict__ owners, int N2, int K,
+                                               const double* __restrict__ part,
+                                               const double* __restrict__ cpow, double lr,
+                                               float* __restrict__ table16)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = (int)(gid & 3);
-    const size_t e = gid >> 2;
-    if (e >= (size_t)F * N2) return;
-    const int4 r = rec[e];
-    const int pos = (int)(e % N2);
-    if (r.x < 0 || pos != r.z) return;                 // only the head of a segment
-    const double cm = cpow[r.w - r.z];
-    unsigned long long* a = accum + e * SLOT + 4 * q;
-    float* row = table16 + (size_t)r.x * SLOT + 4 * q;
+    __shared__ double s_sum[16][16];
+    const int n = *owner_cnt;
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int NQ = N2 >> 4;
+    for (int o = blockIdx.x; o < n; o += gridDim.x) {
+        const int4 ow = owners[o];                         // {f, s, e, row}
+        const int q0 = ow.y >> 4, q1 = (ow.z - 1) >> 4;
+        double sum = 0.0;
+        for (int q = q0 + grp; q <= q1; q += 16)
+            sum += part[(((size_t)ow.x * NQ + q) * 2 + (q == q0 ? 1 : 0)) * SLOT + l];
+        s_sum[grp][l] = sum;
+        __syncthreads();
+        if (grp == 0 && l < K) {
+            double tot = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (4 * q + j < K) {
-            const double s = (double)(long long)a[j] * (1.0 / FIX_SCALE);
-            row[j] = (float)((double)row[j] * cm + s);
-            a[j] = 0ull;
+            for (int gI = 0; gI < 16; ++gI) tot += s_sum[gI][l];
+            float* p = table16 + (size_t)ow.w * SLOT + l;
+            *p = (float)((double)*p * cpow[ow.z - ow.y] - lr * tot);
         }
+        __syncthreads();
+    }
 }
 
 // helpers for fnn_set_table / fnn_get_table / fnn_get_rows
