@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -39,6 +40,7 @@ struct fnn_handle {
     size_t n1 = 0, n2 = 0, nw12 = 0, nw = 0;
     int splitk = 8;
     bool bf16 = false;
+    bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
     // FM table
     float* table16 = nullptr; int32_t* field_of_row = nullptr; int64_t n_rows = 0; float w0 = 0.f;
     // dense
@@ -124,10 +126,9 @@ int update_cpow(fnn_handle* h, int b_size, int B) {
 }
 
 template <typename T, int NT, typename Epi>
-void launch_gemm(hipStream_t s, const T* A, int lda, const T* Bt, int ldb, int M, int N, int klen,
-                 int splitk, Epi epi) {
-    dim3 grid(M / 64, N / (16 * NT), splitk);
-    hipLaunchKernelGGL((k_gemm<T, NT, Epi>), grid, dim3(256), 0, s, A, lda, Bt, ldb, klen, epi);
+void launch_gemm(hipStream_t s, const T* A, int lda, const T* Bft, int M, int N, int klen, Epi epi) {
+    dim3 grid(M / 64, N / (16 * NT), 1);
+    hipLaunchKernelGGL((k_gemm<T, NT, Epi>), grid, dim3(256), 0, s, A, lda, Bft, klen, epi);
 }
 
 // refresh shadows from the masters without a gradient step
@@ -135,6 +136,24 @@ template <typename T> void launch_update(fnn_handle* h, const float* bucket, flo
     const size_t n = h->nw;
     hipLaunchKernelGGL((k_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->master,
                        bucket, lr, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t);
+}
+
+template <typename T, int C1, int C2, int CX>
+void launch_mlp_inst(hipStream_t s, int nblk, const MlpArgs<T>& a) {
+    constexpr int PAD = 16 / (int)sizeof(T);
+    constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
+    const size_t lds = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
+    hipLaunchKernelGGL((k_mlp<T, C1, C2, CX>), dim3(nblk), dim3(256), lds, s, a);
+}
+// the strip kernel is instantiated for the padded shapes in use; anything else takes the
+// layer-by-layer kernels
+bool mlp_shape_ok(const fnn_handle* h) {
+    const int c1 = h->H1p / 64, c2 = h->H2p / 64, cx = h->K1p / 64;
+    return cx == 4 && ((c1 == 5 && c2 == 2) || (c1 == 1 && c2 == 1));
+}
+template <typename T> void launch_mlp(fnn_handle* h, int nblk, const MlpArgs<T>& a) {
+    if (h->H1p / 64 == 5) launch_mlp_inst<T, 5, 2, 4>(h->st, nblk, a);
+    else launch_mlp_inst<T, 1, 1, 4>(h->st, nblk, a);
 }
 
 // gather + forward (+ backward when train).  Everything on h->st except the id sort.
@@ -165,6 +184,15 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
         }
         HIPCHK(h, hipEventRecord(h->ev_join, h->st_side));
     }
+    if (h->fused && mlp_shape_ok(h)) {
+        ProfScope ps(h, "mlp", h->st);
+        MlpArgs<T> a{ids, y, B, F, K, h->table16, h->n_rows, h->w0,
+                     (const T*)h->w1, (const T*)h->w1t, (const T*)h->w2, (const T*)h->w2t, h->master + h->nw12,
+                     m1, m2, h->cfg.act, train ? ACT_TANH : h->cfg.act, h->H1, h->H2, train ? 1 : 0,
+                     xpT, d1T, d2T, dl1T, dl2T, dl3T, ldT, h->gxp, p_out, h->loss_t, h->err_flag};
+        launch_mlp<T>(h, Ba / 16, a);
+        if (!train) return FNN_OK;
+    } else {
     {   // A3
         ProfScope ps(h, "gather", h->st);
         const int nthreads = Ba * F;
@@ -174,12 +202,12 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     {   // A4 layer 1: d1 = act(x' W1p) * r1
         ProfScope ps(h, "fwd1", h->st);
         EpiFwd<T> e{d1, H1p, train ? d1T : nullptr, ldT, m1, h->cfg.act, h->H1, B};
-        launch_gemm<T, 4>(h->st, xp, K1p, (const T*)h->w1t, K1p, Ba, H1p, K1p, 1, e);
+        launch_gemm<T, 4>(h->st, xp, K1p, (const T*)h->w1t, Ba, H1p, K1p, e);
     }
     {   // A4 layer 2: d2 = tanh(d1 W2p) * r2   (predict: acti_type, no mask)
         ProfScope ps(h, "fwd2", h->st);
         EpiFwd<T> e{d2, H2p, train ? d2T : nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
-        launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, H1p, Ba, H2p, H1p, 1, e);
+        launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, Ba, H2p, H1p, e);
     }
     {   // output unit, loss, delta2
         ProfScope ps(h, "head", h->st);
@@ -191,22 +219,23 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     {   // A5: delta1 = (delta2 W2p^T) * r1 * act'(d1)
         ProfScope ps(h, "bwd1", h->st);
         EpiBwd<T> e{dl1, H1p, dl1T, ldT, d1, m1, h->cfg.act, h->H1, B};
-        launch_gemm<T, 4>(h->st, dl2, H2p, (const T*)h->w2, H2p, Ba, H1p, H2p, 1, e);
+        launch_gemm<T, 4>(h->st, dl2, H2p, (const T*)h->w2, Ba, H1p, H2p, e);
     }
     {   // A5: gx' = delta1 W1p^T
         ProfScope ps(h, "gx", h->st);
         EpiF32 e{h->gxp, K1p, 0};
-        launch_gemm<T, 4>(h->st, dl1, H1p, (const T*)h->w1, H1p, Ba, K1p, H1p, 1, e);
+        launch_gemm<T, 4>(h->st, dl1, H1p, (const T*)h->w1, Ba, K1p, H1p, e);
+    }
     }
     {   // A5: dense gradients, contraction over the examples, split-K slabs
         ProfScope ps(h, "wgrad", h->st);
-        const int klen = Ba / h->splitk;
-        EpiF32 e1{h->slab, H1p, h->nslab};
-        launch_gemm<T, 4>(h->st, xpT, ldT, dl1T, ldT, K1p, H1p, klen, h->splitk, e1);
-        EpiF32 e2{h->slab + h->n1, H2p, h->nslab};
-        launch_gemm<T, 4>(h->st, d1T, ldT, dl2T, ldT, H1p, H2p, klen, h->splitk, e2);
-        EpiF32 e3{h->slab + h->nw12, 16, h->nslab};       // gw3p = d2^T delta3 (column 0)
-        launch_gemm<T, 1>(h->st, d2T, ldT, dl3T, ldT, H2p, 16, klen, h->splitk, e3);
+        WgradArgs wa;
+        wa.p[0] = WgradProb{xpT, dl1T, h->slab, K1p / 64, H1p / 64, H1p};
+        wa.p[1] = WgradProb{d1T, dl2T, h->slab + h->n1, H1p / 64, H2p / 64, H2p};
+        wa.p[2] = WgradProb{d2T, dl3T, h->slab + h->nw12, H2p / 64, 1, 64};     // gw3p = column 0
+        wa.ldT = ldT; wa.klen = Ba / h->splitk; wa.zstride = h->nslab;
+        const int nblk = wa.p[0].mt * wa.p[0].nt + wa.p[1].mt * wa.p[1].nt + wa.p[2].mt * wa.p[2].nt;
+        hipLaunchKernelGGL((k_wgrad<T>), dim3(nblk, h->splitk), dim3(256), 0, h->st, wa);
     }
     {
         ProfScope ps(h, "reduce", h->st);
@@ -290,10 +319,11 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
     h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
     h->bf16 = cfg->precision == FNN_PREC_BF16;
+    if (const char* ev = getenv("FNN_NO_FUSE")) h->fused = !(ev[0] == '1');
     const size_t ts = tsize(h), Ba = h->ldT;
     CK(alloc_dev(h, &h->master, h->nw));
     CK(alloc_dev(h, &h->bucket, h->nw));
-    h->nslab = h->nw12 + (size_t)h->H2p * 16;
+    h->nslab = h->nw12 + (size_t)h->H2p * 64;
     CK(alloc_dev(h, &h->slab, (size_t)h->splitk * h->nslab));
     CK(alloc_dev(h, (char**)&h->w1, h->n1 * ts));   CK(alloc_dev(h, (char**)&h->w1t, h->n1 * ts));
     CK(alloc_dev(h, (char**)&h->w2, h->n2 * ts));   CK(alloc_dev(h, (char**)&h->w2t, h->n2 * ts));
@@ -305,7 +335,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, &h->gxp, Ba * h->K1p));
     CK(alloc_dev(h, &h->p_buf, Ba));
     CK(alloc_dev(h, (char**)&h->d2T, Ba * h->H2p * ts));
-    CK(alloc_dev(h, (char**)&h->dl3T, Ba * 16 * ts));
+    CK(alloc_dev(h, (char**)&h->dl3T, Ba * 64 * ts));
     CK(alloc_dev(h, &h->loss_t, Ba));
     CK(alloc_dev(h, &h->loss_dev, (size_t)1));
     CK(alloc_dev(h, &h->rec, (size_t)h->F * h->N2max));

@@ -10,8 +10,10 @@
 //   W1p      [K1p][H1p], W2p [H1p][H2p], w3p [H2p]: dense tensors padded the same way, the
 //                                 bias of each layer stored as the weight row of the "ones"
 //                                 column of its input (b1 = W1p[16+K], b2 = W2p[H1], b3 = w3p[H2]).
-//   Every activation is kept row-major [Ba][N] (A operand of the next GEMM) and transposed
-//   [N][ldT] (operands of the weight-gradient GEMMs, whose contraction runs over examples).
+//   Global MFMA operands (weight shadows in both orientations, and the transposed activations
+//   that feed the weight-gradient products) are stored FRAGMENT-TILED: the 16 rows x KS k-values
+//   one MFMA fragment covers are 1 KiB contiguous in lane order (ft_off below), so a wave's
+//   fragment load is one fully coalesced 16 B/lane read instead of 16 separate 64-B row pieces.
 //
 // All matrix products run on the matrix cores: v_mfma_f32_16x16x32_bf16 (FNN_PREC_BF16) or the
 // exact-f32 v_mfma_f32_16x16x4_f32 (FNN_PREC_F32, the parity mode).
@@ -55,6 +57,18 @@ __device__ inline void mma(f32x4& acc, const f32x4 a, const f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// Fragment-tiled operand layout for a [rows][Ktot] operand whose k index is the contraction index:
+// element (row, k) lives at ((row/16 * Ktot/KS + k/KS) * 64 + lane) * EPL + k % EPL with
+// lane = row%16 + 16 * ((k % KS) / EPL)  -- exactly the MFMA operand map above.
+template <typename T> __host__ __device__ inline size_t ft_off(int row, int k, int Ktot) {
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    return ((size_t)((row >> 4) * (Ktot / KS) + k / KS) * 64 + (row & 15) + 16 * ((k % KS) / EPL)) * EPL + (k % EPL);
+}
+// pointer to the fragment of row-tile `rt`, k-step `kt` for lane `lane`
+template <typename T> __device__ inline const T* ft_frag(const T* base, int rt, int kt, int nkt, int lane) {
+    return base + ((size_t)(rt * nkt + kt) * 64 + lane) * Traits<T>::EPL;
 }
 
 __device__ inline void store4(float* p, float a, float b, float c, float d) {
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ ids,
         store4(xp + (size_t)(t0 + i) * K1p + c0, v[i][0], v[i][1], v[i][2], v[i][3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        store4(xpT + (size_t)(c0 + j) * ldT + t0, v[0][j], v[1][j], v[2][j], v[3][j]);
+        store4(xpT + ft_off<T>(c0 + j, t0, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
 }
 
 // Reference-layout gather for fnn_gather(): x [B][1+F*K] float (python/FNN_wnzh.py:91-96).
@@ -176,7 +190,7 @@ template <typename T> struct EpiFwd {        // A4: act(z) * mask, ones column, 
             v[r] = (row0 + r < B) ? x : 0.0f;
             out[(size_t)(row0 + r) * ld + col] = (T)v[r];
         }
-        if (outT) store4(outT + (size_t)col * ldT + row0, v[0], v[1], v[2], v[3]);
+        if (outT) store4(outT + ft_off<T>(col, row0, ldT), v[0], v[1], v[2], v[3]);
     }
 };
 template <typename T> struct EpiBwd {        // A5: delta = (delta_next * W^T) * mask * act'(d)
@@ -192,7 +206,7 @@ template <typename T> struct EpiBwd {        // A5: delta = (delta_next * W^T) *
             v[r] = (row0 + r < B && col < H) ? x : 0.0f;
             out[(size_t)(row0 + r) * ld + col] = (T)v[r];
         }
-        store4(outT + (size_t)col * ldT + row0, v[0], v[1], v[2], v[3]);
+        store4(outT + ft_off<T>(col, row0, ldT), v[0], v[1], v[2], v[3]);
     }
 };
 struct EpiF32 {                               // plain float output (gx', split-K slabs)
@@ -206,32 +220,316 @@ struct EpiF32 {                               // plain float output (gx', split-
 
 template <typename T, int NT, typename Epi>
 __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
-                                              const T* __restrict__ Bt, int ldb, int klen, Epi epi)
+                                              const T* __restrict__ Bft, int klen, Epi epi)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * 16;
-    const int col0 = blockIdx.y * (16 * NT);
-    const size_t k0 = (size_t)blockIdx.z * klen + (lane >> 4) * EPL;
-    const T* ap = A + (size_t)(row0 + (lane & 15)) * lda + k0;
-    const T* bp = Bt + (size_t)(col0 + (lane & 15)) * ldb + k0;
+    const int ct0 = blockIdx.y * NT;                  // first 16-column tile of this strip
+    const T* ap = A + (size_t)(row0 + (lane & 15)) * lda + (lane >> 4) * EPL;
+    const int nkt = klen / KS;
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int k = 0; k < klen; k += KS) {
-        const frag a = *reinterpret_cast<const frag*>(ap + k);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const frag a = *reinterpret_cast<const frag*>(ap + kt * KS);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const frag b = *reinterpret_cast<const frag*>(bp + (size_t)n * 16 * ldb + k);
+            const frag b = *reinterpret_cast<const frag*>(ft_frag<T>(Bft, ct0 + n, kt, nkt, lane));
             mma(acc[n], a, b);
         }
     }
     // C/D map of the 16x16 shapes: col = lane & 15, row = 4*(lane >> 4) + reg.
     const int r0 = row0 + 4 * (lane >> 4);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) epi(r0, col0 + n * 16 + (lane & 15), acc[n], blockIdx.z);
+    for (int n = 0; n < NT; ++n) epi(r0, (ct0 + n) * 16 + (lane & 15), acc[n], 0);
+}
+
+// Weight gradients: gw = P^T Q with the contraction over the examples t (python/FNN_wnzh.py:174),
+// for the three products of a step in ONE launch: x'^T delta1, d1^T delta2, d2^T delta3.  Both
+// operands are fragment-tiled transposed activations.  A workgroup owns a 64 x 64 output block of
+// one product and one K slice (blockIdx.y); partial sums go to that slice's f32 slab.
+struct WgradProb { const void* A; const void* B; float* out; int mt, nt, ldo; };   // mt, nt: 64-blocks
+struct WgradArgs { WgradProb p[3]; int ldT, klen; size_t zstride; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a)
+{
+    typedef typename Traits<T>::frag frag;
+    constexpr int KS = Traits<T>::KS;
+    int b = blockIdx.x, pi = 0;
+    while (pi < 2 && b >= a.p[pi].mt * a.p[pi].nt) { b -= a.p[pi].mt * a.p[pi].nt; ++pi; }
+    const WgradProb pr = a.p[pi];
+    const int bm = b / pr.nt, bn = b % pr.nt;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rt = bm * 4 + wave, ct0 = bn * 4;
+    const int nkt_all = a.ldT / KS, kt0 = blockIdx.y * (a.klen / KS), nkt = a.klen / KS;
+    const T* A = static_cast<const T*>(pr.A);
+    const T* B = static_cast<const T*>(pr.B);
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kt = 0; kt < nkt; ++kt) {
+        const frag af = *reinterpret_cast<const frag*>(ft_frag<T>(A, rt, kt0 + kt, nkt_all, lane));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(B, ct0 + n, kt0 + kt, nkt_all, lane));
+            mma(acc[n], af, bf);
+        }
+    }
+    float* o = pr.out + (size_t)blockIdx.y * a.zstride;
+    const int r0 = rt * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = (ct0 + n) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(size_t)(r0 + r) * pr.ldo + col] = acc[n][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused MLP strip kernel: A3 gather -> A4 forward -> loss -> A5 backward-data for 16 examples per
+// workgroup, in ONE launch (python/FNN_wnzh.py:144-174 + :87-96).  The six products that the
+// reference's Theano graph runs one after another (x.w1, d1.w2, d2.w3, delta2.w2^T, delta1.w1^T)
+// never leave the CU: the strip's activations live in LDS (padded rows, conflict-free
+// ds_read_b128 fragments), each of the 4 waves owns a quarter of every layer's output columns,
+// and the weights stream from L2 straight into B fragments.  What goes back to HBM is only what
+// later kernels need: the transposed activations for the weight-gradient GEMMs, gx' for the
+// sparse-row update, p / loss.  Dimensions are compile-time: K1p = 64*CX, H1p = 64*C1,
+// H2p = 64*C2.
+// ------------------------------------------------------------------------------------------
+template <typename T> struct MlpArgs {
+    const int32_t* ids; const float* y; int B, F, K; const float* table16; int64_t n_rows; float w0;
+    const T *w1, *w1t, *w2, *w2t; const float* w3p; const uint8_t *m1, *m2;
+    int act1, act2, H1, H2, train;
+    T *xpT, *d1T, *d2T, *dl1T, *dl2T, *dl3T; int ldT;
+    float *gxp, *p_out, *loss_t; int* err;
+};
+
+template <typename T, int C1, int C2, int CX>
+__global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
+{
+    typedef typename Traits<T>::frag frag;
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    constexpr int K1p = 64 * CX, H1p = 64 * C1, H2p = 64 * C2;
+    constexpr int PAD = 16 / (int)sizeof(T);
+    constexpr int LX = K1p + PAD, L1 = H1p + PAD, L2 = H2p + PAD;
+    constexpr int LXM = LX > L1 ? LX : L1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* sx = reinterpret_cast<T*>(smem);          // [16][LXM]  x' tile, later delta1 (stride L1)
+    T* sd1 = sx + 16 * LXM;                      // [16][L1]   d1
+    T* sdl2 = sd1 + 16 * L1;                     // [16][L2]   delta2
+    float* sz = reinterpret_cast<float*>(sdl2 + 16 * L2);   // [4][16]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int t0 = blockIdx.x * 16;
+    const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
+
+    // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96)
+    for (int e = tid; e < 16 * F; e += 256) {
+        const int q = e & 3, f = (e >> 2) % F, tq = (e >> 2) / F;
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + 4 * tq + i;
+            int64_t id = -1;
+            if (t < B) {
+                id = a.ids[(size_t)t * F + f];
+                if (id < -1 || id >= a.n_rows) { atomicOr(a.err, 1); id = -1; }
+            }
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0) r = *reinterpret_cast<const float4*>(a.table16 + (size_t)id * SLOT + 4 * q);
+            v[i][0] = r.x; v[i][1] = r.y; v[i][2] = r.z; v[i][3] = r.w;
+            if (t < B && q == (K >> 2)) {
+                if (f == 0) v[i][K & 3] = a.w0;
+                if (f == 1) v[i][K & 3] = 1.0f;
+            }
+        }
+        const int c0 = f * SLOT + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store4(sx + (4 * tq + i) * LX + c0, v[i][0], v[i][1], v[i][2], v[i][3]);
+        if (a.train) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                store4(a.xpT + ft_off<T>(c0 + j, t0 + 4 * tq, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
+        }
+    }
+    for (int e = tid; e < 16 * (K1p - F * SLOT); e += 256) {       // pad columns of the tile
+        const int r = e / (K1p - F * SLOT), c = F * SLOT + e % (K1p - F * SLOT);
+        sx[r * LX + c] = (T)0.f;
+    }
+    __syncthreads();
+
+    // ---- P1: d1 = act(x' W1p) * r1   (:147-155)
+    float d1v[C1][4];
+    {
+        f32x4 acc[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* ap = sx + lr * LX + lq * EPL;
+#pragma unroll
+        for (int kk = 0; kk < K1p / KS; ++kk) {
+            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+#pragma unroll
+            for (int i = 0; i < C1; ++i) {
+                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, K1p / KS, lane));
+                mma(acc[i], af, bf);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int col = (wave * C1 + i) * 16 + lr;
+            float m = 0.f;
+            if (col < a.H1) m = a.m1 ? (float)a.m1[col] : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float x = (col < a.H1) ? act_fn(acc[i][r], a.act1) * m : (col == a.H1 ? 1.0f : 0.0f);
+                const float v = (t0 + row < B) ? x : 0.0f;
+                d1v[i][r] = v;
+                sd1[row * L1 + col] = (T)v;
+            }
+            if (a.train) store4(a.d1T + ft_off<T>(col, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
+        }
+    }
+    __syncthreads();
+
+    // ---- P2: d2 = act2(d1 W2p) * r2, z3 = d2 . w3p   (:164-169)
+    float d2v[C2][4], zp[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 acc[C2];
+#pragma unroll
+        for (int i = 0; i < C2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* ap = sd1 + lr * L1 + lq * EPL;
+#pragma unroll
+        for (int kk = 0; kk < H1p / KS; ++kk) {
+            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+#pragma unroll
+            for (int i = 0; i < C2; ++i) {
+                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, H1p / KS, lane));
+                mma(acc[i], af, bf);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const int col = (wave * C2 + i) * 16 + lr;
+            float m = 0.f;
+            if (col < a.H2) m = a.m2 ? (float)a.m2[col] : 1.0f;
+            const float w3 = a.w3p[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                const float x = (col < a.H2) ? act_fn(acc[i][r], a.act2) * m : (col == a.H2 ? 1.0f : 0.0f);
+                const float v = (t0 + row < B) ? x : 0.0f;
+                d2v[i][r] = v;
+                zp[r] += v * w3;
+            }
+            if (a.train) store4(a.d2T + ft_off<T>(col, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        zp[r] += __shfl_xor(zp[r], 1); zp[r] += __shfl_xor(zp[r], 2);
+        zp[r] += __shfl_xor(zp[r], 4); zp[r] += __shfl_xor(zp[r], 8);
+        if (lr == 0) sz[wave * 16 + 4 * lq + r] = zp[r];
+    }
+    __syncthreads();
+    float d3[4], ls[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r, t = t0 + row;
+        const float z = sz[row] + sz[16 + row] + sz[32 + row] + sz[48 + row];
+        const float p = 1.0f / (1.0f + expf(-z));
+        d3[r] = 0.f; ls[r] = 0.f;
+        if (t < B) {
+            if (a.p_out && wave == 0 && lr == 0) a.p_out[t] = p;
+            if (a.train) {
+                const float yy = a.y[t];
+                d3[r] = p - yy;
+                ls[r] = fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))) - yy * z;   // = -y log p - (1-y) log(1-p)
+            }
+        }
+    }
+    if (!a.train) return;
+    if (wave == 0 && lr == 0) {
+        store4(a.dl3T + ft_off<T>(0, t0 + 4 * lq, ldT), d3[0], d3[1], d3[2], d3[3]);
+        store4(a.loss_t + t0 + 4 * lq, ls[0], ls[1], ls[2], ls[3]);
+    }
+    // delta2 = delta3 * w3 * r2 * (1 - d2^2)   (layer 2 is tanh on the dropout path, :165)
+#pragma unroll
+    for (int i = 0; i < C2; ++i) {
+        const int col = (wave * C2 + i) * 16 + lr;
+        float m = 0.f;
+        if (col < a.H2) m = a.m2 ? (float)a.m2[col] : 1.0f;
+        const float w3m = a.w3p[col] * m;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = d3[r] * w3m * (1.0f - d2v[i][r] * d2v[i][r]);
+            sdl2[(4 * lq + r) * L2 + col] = (T)v[r];
+        }
+        store4(a.dl2T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+
+    // ---- P3: delta1 = (delta2 W2p^T) * r1 * act'(d1)
+    T* sdl1 = sx;                                       // the x' tile is dead since P1
+    {
+        f32x4 acc[C1];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* ap = sdl2 + lr * L2 + lq * EPL;
+#pragma unroll
+        for (int kk = 0; kk < H2p / KS; ++kk) {
+            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+#pragma unroll
+            for (int i = 0; i < C1; ++i) {
+                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, H2p / KS, lane));
+                mma(acc[i], af, bf);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int col = (wave * C1 + i) * 16 + lr;
+            float m = 0.f;
+            if (col < a.H1) m = a.m1 ? (float)a.m1[col] : 1.0f;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r;
+                v[r] = (t0 + row < B) ? acc[i][r] * m * dact_fn(d1v[i][r], a.act1) : 0.0f;
+                sdl1[row * L1 + col] = (T)v[r];
+            }
+            store4(a.dl1T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+
+    // ---- P4: gx' = delta1 W1p^T   (what `train` returns first, :174,:179)
+    {
+        f32x4 acc[CX];
+#pragma unroll
+        for (int i = 0; i < CX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* ap = sdl1 + lr * L1 + lq * EPL;
+#pragma unroll
+        for (int kk = 0; kk < H1p / KS; ++kk) {
+            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+#pragma unroll
+            for (int i = 0; i < CX; ++i) {
+                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, H1p / KS, lane));
+                mma(acc[i], af, bf);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CX; ++i) {
+            const int col = (wave * CX + i) * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -287,7 +585,7 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
     }
     if (!train) return;
     if (c16 == 0) {
-        store4(dl3T + row0, d3[0], d3[1], d3[2], d3[3]);
+        store4(dl3T + ft_off<T>(0, row0, ldT), d3[0], d3[1], d3[2], d3[3]);
         store4(loss_t + row0, ls[0], ls[1], ls[2], ls[3]);
     }
     for (int cb = 0; cb < H2p; cb += 64) {
@@ -309,14 +607,14 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            store4(dl2T + (size_t)(c + j) * ldT + row0, o[0][j], o[1][j], o[2][j], o[3][j]);
+            store4(dl2T + ft_off<T>(c + j, row0, ldT), o[0][j], o[1][j], o[2][j], o[3][j]);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Dense gradient bucket: sum the split-K slabs in a fixed order, add the L2 term 2*lambda1*theta
 // (python/FNN_wnzh.py:173; SNN: all six tensors); the last block sums the per-example losses.
-// Slab z = [W1p grads n1 | W2p grads n2 | gw3p as column 0 of an [H2p][16] tile].
+// Slab z = [W1p grads n1 | W2p grads n2 | gw3p as column 0 of an [H2p][64] tile].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, int splitk,
                                                 size_t nw_all, size_t nw12, size_t nslab,
@@ -339,7 +637,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, 
     }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw_all) return;
-    const size_t src = (i < nw12) ? i : nw12 + (i - nw12) * 16;
+    const size_t src = (i < nw12) ? i : nw12 + (i - nw12) * 64;
     float g = 0.f;
 #pragma unroll 8
     for (int z = 0; z < splitk; ++z) g += slab[(size_t)z * nslab + src];
@@ -348,7 +646,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, 
 }
 
 // theta <- theta - lr * g  (python/FNN_wnzh.py:179-182) on the f32 masters, then refresh the
-// compute-precision shadows in both orientations (forward wants W^T k-contiguous, backward W).
+// compute-precision shadows in both orientations, fragment-tiled (ft_off).
 template <typename T>
 __global__ void k_update(float* __restrict__ master, const float* __restrict__ bucket, float lr,
                          int K1p, int H1p, int H2p, T* __restrict__ w1, T* __restrict__ w1t,
@@ -359,13 +657,15 @@ __global__ void k_update(float* __restrict__ master, const float* __restrict__ b
     if (i >= n1 + n2 + H2p) return;
     float w = master[i];
     if (bucket) { w -= lr * bucket[i]; master[i] = w; }
-    if (i < n1) {
+    if (i < n1) {           // W1p[r = x' slot][c = h1 unit]
         const int r = (int)(i / H1p), c = (int)(i % H1p);
-        w1[i] = (T)w; w1t[(size_t)c * K1p + r] = (T)w;
-    } else if (i < n1 + n2) {
+        w1t[ft_off<T>(c, r, K1p)] = (T)w;      // forward:  output column c, contraction over r
+        w1[ft_off<T>(r, c, H1p)] = (T)w;       // gx:       output column r, contraction over c
+    } else if (i < n1 + n2) {                  // W2p[r = h1 unit][c = h2 unit]
         const size_t j = i - n1;
         const int r = (int)(j / H2p), c = (int)(j % H2p);
-        w2[j] = (T)w; w2t[(size_t)c * H1p + r] = (T)w;
+        w2t[ft_off<T>(c, r, H1p)] = (T)w;      // forward
+        w2[ft_off<T>(r, c, H2p)] = (T)w;       // delta1
     }
 }
 

@@ -119,6 +119,28 @@ def test_train_step_f32_vs_oracle(built, B, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("prec", ['f32', 'bf16'])
+def test_layer_by_layer_path_matches_strip_kernel(built, prec, monkeypatch):
+    """FNN_NO_FUSE=1 selects the layer-by-layer kernels (the path for shapes the fused strip
+    kernel is not instantiated for); both paths must agree with the oracle and with each other."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(300, seed=17, dup_col=6, empty=[(1, 2)])
+    outs = []
+    for nofuse in ('0', '1'):
+        monkeypatch.setenv('FNN_NO_FUSE', nofuse)
+        eng = make_engine(rows, fo, p, prec=prec, lr=0.01, lam1=0.02)
+        if prec == 'f32':
+            _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.02, 0.1)
+        else:
+            eng.train_step(ids, y, r1, r2)
+        outs.append((eng.get_table(), eng.get_dense(), eng.predict(ids).cpu().numpy()))
+        eng.close()
+    tol = 1e-6 if prec == 'f32' else 2e-3
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=tol, atol=tol * 1e-1)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=tol * 10, atol=tol)
+    for k in ('w1', 'w2', 'w3'):
+        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=tol * 10, atol=tol)
+
+
 def test_train_step_f32_global_batch_decay(built):
     """Data-parallel callers pass the GLOBAL batch length for the decay constant (:304)."""
     rows, fo, ids, y, p, r1, r2 = make_problem(50, seed=3)
