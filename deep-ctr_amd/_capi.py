@@ -44,6 +44,7 @@ SIGNATURES = {
     "fnn_get_dense": (_i, [_vp, _i, _vp, _vp, _i]),
     "fnn_gather": (_i, [_vp, _vp, _i, _vp, _i]),
     "fnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.POINTER(_f)]),
+    "fnn_prefetch_ids": (_i, [_vp, _vp, _i]),
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "fnn_step_end": (_i, [_vp, C.POINTER(_f)]),

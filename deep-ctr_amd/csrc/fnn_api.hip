@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "../../include/fnn_hip.h"
-#include "fnn_kernels.hip.h"
+#include "fnn_step_kernels.hip.h"
 
 using namespace fnn;
 
@@ -31,9 +31,8 @@ struct fnn_handle {
     fnn_cfg cfg{};
     std::string err;
     int dev = 0;
-    hipStream_t st = nullptr, st_side = nullptr;
+    hipStream_t st = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // shapes
     int F = 0, K = 0, H1 = 0, H2 = 0, xdim = 0, K1p = 0, H1p = 0, H2p = 0;
     int Bmax = 0, ldT = 0, N2max = 0;
@@ -54,7 +53,13 @@ struct fnn_handle {
     void *d2T = nullptr, *dl3T = nullptr;
     size_t nslab = 0;
     // scatter
-    int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr;
+    // Grouping results (sorted (row, t) records + level-2 work lists), double-buffered: the slot of
+    // the batch being trained and the slot the NEXT batch is grouped into during this step.
+    struct SortSlot { int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr; };
+    SortSlot slot[2]; int cur = 0;
+    const int32_t* sorted_ids = nullptr; int sorted_B = 0;      // what slot[cur] holds (nullptr: nothing)
+    const int32_t* next_ids = nullptr; int next_B = 0;          // pending fnn_prefetch_ids request
+    bool key64 = false;
     double* cpow_dev = nullptr;
     std::vector<double> cpow_host; double cpow_c = -1.0; int cpow_n = 0;
     int* err_flag = nullptr;
@@ -62,7 +67,8 @@ struct fnn_handle {
     int32_t* st_ids = nullptr; float* st_y = nullptr; uint8_t* st_m1 = nullptr; uint8_t* st_m2 = nullptr;
     float* st_p = nullptr; float* st_x = nullptr;
     // step state
-    bool in_step = false; int step_B = 0;
+    bool in_step = false, update_pending = false; int step_B = 0;
+    int prefetch_hits = 0, prefetch_misses = 0;
     // profiling
     bool prof = false;
     std::map<std::string, ProfSlot> prof_slots;
@@ -138,25 +144,114 @@ template <typename T> void launch_update(fnn_handle* h, const float* bucket, flo
                        bucket, lr, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t);
 }
 
-template <typename T, int C1, int C2, int CX>
-void launch_mlp_inst(hipStream_t s, int nblk, const MlpArgs<T>& a) {
-    constexpr int PAD = 16 / (int)sizeof(T);
-    constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
-    const size_t lds = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
-    hipLaunchKernelGGL((k_mlp<T, C1, C2, CX>), dim3(nblk), dim3(256), lds, s, a);
-}
 // the strip kernel is instantiated for the padded shapes in use; anything else takes the
 // layer-by-layer kernels
 bool mlp_shape_ok(const fnn_handle* h) {
     const int c1 = h->H1p / 64, c2 = h->H2p / 64, cx = h->K1p / 64;
     return cx == 4 && ((c1 == 5 && c2 == 2) || (c1 == 1 && c2 == 1));
 }
-template <typename T> void launch_mlp(fnn_handle* h, int nblk, const MlpArgs<T>& a) {
-    if (h->H1p / 64 == 5) launch_mlp_inst<T, 5, 2, 4>(h->st, nblk, a);
-    else launch_mlp_inst<T, 1, 1, 4>(h->st, nblk, a);
+int sort_n2(int B) { int N2 = 256; while (N2 < B) N2 <<= 1; return N2; }
+
+template <typename T> WgradArgs make_wgrad_args(fnn_handle* h, int Ba) {
+    WgradArgs wa;
+    wa.p[0] = WgradProb{h->xpT, h->dl1T, h->slab, h->K1p / 64, h->H1p / 64, h->H1p};
+    wa.p[1] = WgradProb{h->d1T, h->dl2T, h->slab + h->n1, h->H1p / 64, h->H2p / 64, h->H2p};
+    wa.p[2] = WgradProb{h->d2T, h->dl3T, h->slab + h->nw12, h->H2p / 64, 1, 64};     // gw3p = column 0
+    wa.ldT = h->ldT; wa.klen = Ba / h->splitk; wa.zstride = h->nslab;
+    return wa;
+}
+int wgrad_blocks(const WgradArgs& wa) {
+    return wa.p[0].mt * wa.p[0].nt + wa.p[1].mt * wa.p[1].nt + wa.p[2].mt * wa.p[2].nt;
+}
+ScatArgs make_scat_args(fnn_handle* h, const fnn_handle::SortSlot& sl, int N2) {
+    return ScatArgs{sl.rec, N2, h->F, h->K, h->gxp, h->K1p, h->cpow_dev, (double)h->cfg.lr, h->table16,
+                    sl.part, sl.owner_cnt, sl.owners};
+}
+template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids, const float* y, int B,
+                                                const uint8_t* m1, const uint8_t* m2, bool train, float* p_out) {
+    return MlpArgs<T>{ids, y, B, h->F, h->K, h->table16, h->n_rows, h->w0,
+                      (const T*)h->w1, (const T*)h->w1t, (const T*)h->w2, (const T*)h->w2t, h->master + h->nw12,
+                      m1, m2, h->cfg.act, train ? ACT_TANH : h->cfg.act, h->H1, h->H2, train ? 1 : 0,
+                      (T*)h->xpT, (T*)h->d1T, (T*)h->d2T, (T*)h->dl1T, (T*)h->dl2T, (T*)h->dl3T, h->ldT,
+                      h->gxp, p_out, h->loss_t, h->err_flag};
+}
+template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes() {
+    constexpr int PAD = 16 / (int)sizeof(T);
+    constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
+    return (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
+}
+template <typename T, int C1, int C2, int CX, typename KT>
+void launch_step1_inst(hipStream_t s, const SortArgs& so, int nmlp, const MlpArgs<T>& a) {
+    size_t lds = mlp_lds_bytes<T, C1, C2, CX>();
+    if (so.nblk > 0 && sort_lds_bytes<KT>() > lds) lds = sort_lds_bytes<KT>();
+    hipLaunchKernelGGL((k_step1<T, C1, C2, CX, KT>), dim3(so.nblk + nmlp), dim3(256), lds, s, so, a);
+}
+template <typename T> void launch_step1(fnn_handle* h, const SortArgs& so, int nmlp, const MlpArgs<T>& a) {
+    const bool big = h->H1p / 64 == 5;
+    if (h->key64) {
+        if (big) launch_step1_inst<T, 5, 2, 4, unsigned long long>(h->st, so, nmlp, a);
+        else launch_step1_inst<T, 1, 1, 4, unsigned long long>(h->st, so, nmlp, a);
+    } else {
+        if (big) launch_step1_inst<T, 5, 2, 4, unsigned>(h->st, so, nmlp, a);
+        else launch_step1_inst<T, 1, 1, 4, unsigned>(h->st, so, nmlp, a);
+    }
+}
+void launch_sort16(fnn_handle* h, const SortArgs& so) {
+    if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(so.nblk), dim3(256),
+                                     sort_lds_bytes<unsigned long long>(), h->st, so);
+    else hipLaunchKernelGGL((k_sort16<unsigned>), dim3(so.nblk), dim3(256), sort_lds_bytes<unsigned>(), h->st, so);
 }
 
-// gather + forward (+ backward when train).  Everything on h->st except the id sort.
+// The fast path: three role-split launches on the main stream (fnn_step_kernels.hip.h).
+template <typename T>
+int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* m1,
+                  const uint8_t* m2, float* p_out, float* gx_out_dev, bool update)
+{
+    const int Ba = rup(B, 256);
+    // grouping of THIS batch: done by the previous step (fnn_prefetch_ids) or right now
+    if (!(h->sorted_ids == ids && h->sorted_B == B)) {
+        h->prefetch_misses++;
+        ProfScope ps(h, "sort_now", h->st);
+        SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F};
+        launch_sort16(h, so);
+    } else h->prefetch_hits++;
+    const bool have_next = h->next_ids != nullptr && !(h->next_ids == ids && h->next_B == B);
+    const int nxt = h->cur ^ 1;
+    {
+        ProfScope ps(h, "step1", h->st);
+        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                    have_next ? h->F : 0};
+        launch_step1<T>(h, so, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out));
+    }
+    if (gx_out_dev) {
+        const size_t n = (size_t)B * h->xdim;
+        hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, h->K1p,
+                           B, h->F, h->K, gx_out_dev);
+    }
+    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    {
+        ProfScope ps(h, "step2", h->st);
+        const WgradArgs wa = make_wgrad_args<T>(h, Ba);
+        const int nwx = wgrad_blocks(wa), nsc = h->F * SORT_N / 256;
+        hipLaunchKernelGGL((k_step2<T>), dim3(nwx * h->splitk + nsc), dim3(256), 0, h->st, wa, nwx, h->splitk, sa);
+    }
+    {
+        ProfScope ps(h, "step3", h->st);
+        const int nred = (int)((h->nw + 255) / 256) + 1;
+        TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
+                    h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
+                    h->w1, h->w1t, h->w2, h->w2t, nred};
+        if (update) hipLaunchKernelGGL((k_step3<T, true>), dim3(nred + 64), dim3(256), 0, h->st, ta, sa);
+        else hipLaunchKernelGGL((k_step3<T, false>), dim3(nred + 64), dim3(256), 0, h->st, ta, sa);
+    }
+    if (have_next) { h->cur = nxt; h->sorted_ids = h->next_ids; h->sorted_B = h->next_B; }
+    else { h->sorted_ids = nullptr; h->sorted_B = 0; }
+    h->next_ids = nullptr; h->next_B = 0;
+    HIPCHK(h, hipGetLastError());
+    return FNN_OK;
+}
+
+// The generic path: one kernel per layer / stage, any padded shape, B up to 16384.
 template <typename T>
 int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* m1,
              const uint8_t* m2, bool train, float* p_out, float* gx_out_dev)
@@ -165,77 +260,66 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     const int F = h->F, K = h->K, K1p = h->K1p, H1p = h->H1p, H2p = h->H2p, ldT = h->ldT;
     T *xp = (T*)h->xp, *xpT = (T*)h->xpT, *d1 = (T*)h->d1, *d1T = (T*)h->d1T, *d2 = (T*)h->d2,
       *dl2 = (T*)h->dl2, *dl2T = (T*)h->dl2T, *dl1 = (T*)h->dl1, *dl1T = (T*)h->dl1T;
-    int N2 = 256; while (N2 < B) N2 <<= 1;
+    const int N2 = sort_n2(B);
     T *d2T = (T*)h->d2T, *dl3T = (T*)h->dl3T;
+    fnn_handle::SortSlot& sl = h->slot[h->cur];
+    h->sorted_ids = nullptr; h->next_ids = nullptr;            // this path keeps no grouping across steps
 
-    if (train) {   // A6 part 1: the sort only needs the ids; run it beside the MLP
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
-        HIPCHK(h, hipStreamWaitEvent(h->st_side, h->ev_fork, 0));
-        {
-            ProfScope ps(h, "sort", h->st_side);
-            const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
-            const dim3 blk(N2 / kpt);
-            if (kpt == 4)
-                hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
-            else if (kpt == 8)
-                hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
-            else
-                hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st_side, ids, B, F, h->n_rows, N2, h->rec, h->owner_cnt);
-        }
-        HIPCHK(h, hipEventRecord(h->ev_join, h->st_side));
+    if (train) {   // A6 part 1: group the (row, t) pairs
+        ProfScope ps(h, "sort", h->st);
+        const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
+        const dim3 blk(N2 / kpt);
+        if (kpt == 4)
+            hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+        else if (kpt == 8)
+            hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+        else
+            hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
     }
     if (h->fused && mlp_shape_ok(h)) {
         ProfScope ps(h, "mlp", h->st);
-        MlpArgs<T> a{ids, y, B, F, K, h->table16, h->n_rows, h->w0,
-                     (const T*)h->w1, (const T*)h->w1t, (const T*)h->w2, (const T*)h->w2t, h->master + h->nw12,
-                     m1, m2, h->cfg.act, train ? ACT_TANH : h->cfg.act, h->H1, h->H2, train ? 1 : 0,
-                     xpT, d1T, d2T, dl1T, dl2T, dl3T, ldT, h->gxp, p_out, h->loss_t, h->err_flag};
-        launch_mlp<T>(h, Ba / 16, a);
+        SortArgs none{nullptr, 0, F, h->n_rows, nullptr, nullptr, 0};
+        launch_step1<T>(h, none, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, train, p_out));
         if (!train) return FNN_OK;
     } else {
-    {   // A3
-        ProfScope ps(h, "gather", h->st);
-        const int nthreads = Ba * F;
-        hipLaunchKernelGGL((k_gather<T>), dim3((nthreads + 255) / 256), dim3(256), 0, h->st, ids, B, Ba,
-                           F, K, h->table16, h->n_rows, h->w0, xp, K1p, xpT, ldT, h->err_flag);
-    }
-    {   // A4 layer 1: d1 = act(x' W1p) * r1
-        ProfScope ps(h, "fwd1", h->st);
-        EpiFwd<T> e{d1, H1p, train ? d1T : nullptr, ldT, m1, h->cfg.act, h->H1, B};
-        launch_gemm<T, 4>(h->st, xp, K1p, (const T*)h->w1t, Ba, H1p, K1p, e);
-    }
-    {   // A4 layer 2: d2 = tanh(d1 W2p) * r2   (predict: acti_type, no mask)
-        ProfScope ps(h, "fwd2", h->st);
-        EpiFwd<T> e{d2, H2p, train ? d2T : nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
-        launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, Ba, H2p, H1p, e);
-    }
-    {   // output unit, loss, delta2
-        ProfScope ps(h, "head", h->st);
-        hipLaunchKernelGGL((k_head<T>), dim3(Ba / 64), dim3(256), 0, h->st, d2, H2p, h->H2,
-                           h->master + h->nw12, m2, y, B, train ? 1 : 0, p_out, dl2, dl2T, ldT, dl3T,
-                           h->loss_t);
-    }
-    if (!train) return FNN_OK;
-    {   // A5: delta1 = (delta2 W2p^T) * r1 * act'(d1)
-        ProfScope ps(h, "bwd1", h->st);
-        EpiBwd<T> e{dl1, H1p, dl1T, ldT, d1, m1, h->cfg.act, h->H1, B};
-        launch_gemm<T, 4>(h->st, dl2, H2p, (const T*)h->w2, Ba, H1p, H2p, e);
-    }
-    {   // A5: gx' = delta1 W1p^T
-        ProfScope ps(h, "gx", h->st);
-        EpiF32 e{h->gxp, K1p, 0};
-        launch_gemm<T, 4>(h->st, dl1, H1p, (const T*)h->w1, Ba, K1p, H1p, e);
-    }
+        {   // A3
+            ProfScope ps(h, "gather", h->st);
+            const int nthreads = Ba * F;
+            hipLaunchKernelGGL((k_gather<T>), dim3((nthreads + 255) / 256), dim3(256), 0, h->st, ids, B, Ba,
+                               F, K, h->table16, h->n_rows, h->w0, xp, K1p, xpT, ldT, h->err_flag);
+        }
+        {   // A4 layer 1: d1 = act(x' W1p) * r1
+            ProfScope ps(h, "fwd1", h->st);
+            EpiFwd<T> e{d1, H1p, train ? d1T : nullptr, ldT, m1, h->cfg.act, h->H1, B};
+            launch_gemm<T, 4>(h->st, xp, K1p, (const T*)h->w1t, Ba, H1p, K1p, e);
+        }
+        {   // A4 layer 2: d2 = tanh(d1 W2p) * r2   (predict: acti_type, no mask)
+            ProfScope ps(h, "fwd2", h->st);
+            EpiFwd<T> e{d2, H2p, train ? d2T : nullptr, ldT, m2, train ? ACT_TANH : h->cfg.act, h->H2, B};
+            launch_gemm<T, 4>(h->st, d1, H1p, (const T*)h->w2t, Ba, H2p, H1p, e);
+        }
+        {   // output unit, loss, delta2
+            ProfScope ps(h, "head", h->st);
+            hipLaunchKernelGGL((k_head<T>), dim3(Ba / 64), dim3(256), 0, h->st, d2, H2p, h->H2,
+                               h->master + h->nw12, m2, y, B, train ? 1 : 0, p_out, dl2, dl2T, ldT, dl3T,
+                               h->loss_t);
+        }
+        if (!train) return FNN_OK;
+        {   // A5: delta1 = (delta2 W2p^T) * r1 * act'(d1)
+            ProfScope ps(h, "bwd1", h->st);
+            EpiBwd<T> e{dl1, H1p, dl1T, ldT, d1, m1, h->cfg.act, h->H1, B};
+            launch_gemm<T, 4>(h->st, dl2, H2p, (const T*)h->w2, Ba, H1p, H2p, e);
+        }
+        {   // A5: gx' = delta1 W1p^T
+            ProfScope ps(h, "gx", h->st);
+            EpiF32 e{h->gxp, K1p, 0};
+            launch_gemm<T, 4>(h->st, dl1, H1p, (const T*)h->w1, Ba, K1p, H1p, e);
+        }
     }
     {   // A5: dense gradients, contraction over the examples, split-K slabs
         ProfScope ps(h, "wgrad", h->st);
-        WgradArgs wa;
-        wa.p[0] = WgradProb{xpT, dl1T, h->slab, K1p / 64, H1p / 64, H1p};
-        wa.p[1] = WgradProb{d1T, dl2T, h->slab + h->n1, H1p / 64, H2p / 64, H2p};
-        wa.p[2] = WgradProb{d2T, dl3T, h->slab + h->nw12, H2p / 64, 1, 64};     // gw3p = column 0
-        wa.ldT = ldT; wa.klen = Ba / h->splitk; wa.zstride = h->nslab;
-        const int nblk = wa.p[0].mt * wa.p[0].nt + wa.p[1].mt * wa.p[1].nt + wa.p[2].mt * wa.p[2].nt;
-        hipLaunchKernelGGL((k_wgrad<T>), dim3(nblk, h->splitk), dim3(256), 0, h->st, wa);
+        const WgradArgs wa = make_wgrad_args<T>(h, Ba);
+        hipLaunchKernelGGL((k_wgrad<T>), dim3(wgrad_blocks(wa), h->splitk), dim3(256), 0, h->st, wa);
     }
     {
         ProfScope ps(h, "reduce", h->st);
@@ -248,19 +332,15 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
         hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, K1p,
                            B, F, K, gx_out_dev);
     }
-    // A6 part 2
-    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));
+    const ScatArgs sa = make_scat_args(h, sl, N2);           // A6 part 2
     {
         ProfScope ps(h, "scatter", h->st);
-        const size_t nthr = (size_t)F * N2;                 // 16 lanes per chunk of 16 entries
-        hipLaunchKernelGGL(k_scat1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, h->rec, N2, F, K,
-                           h->gxp, K1p, h->cpow_dev, (double)h->cfg.lr, h->table16, h->part, h->owner_cnt,
-                           h->owners);
+        const size_t nthr = (size_t)F * N2;                  // 16 lanes per chunk of 16 entries
+        hipLaunchKernelGGL(k_scat1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, h->st, sa);
     }
     {
         ProfScope ps(h, "finalize", h->st);
-        hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, h->owner_cnt, h->owners, N2, K, h->part,
-                           h->cpow_dev, (double)h->cfg.lr, h->table16);
+        hipLaunchKernelGGL(k_scat2, dim3(64), dim3(256), 0, h->st, sa);
     }
     HIPCHK(h, hipGetLastError());
     return FNN_OK;
@@ -308,9 +388,6 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     HK(hipSetDevice(h->dev));
     if (cfg->stream) { h->st = (hipStream_t)cfg->stream; h->own_stream = false; }
     else { HK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking)); h->own_stream = true; }
-    HK(hipStreamCreateWithFlags(&h->st_side, hipStreamNonBlocking));
-    HK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     h->F = cfg->n_fields; h->K = cfg->k; h->H1 = cfg->hidden1; h->H2 = cfg->hidden2;
     h->xdim = 1 + h->F * h->K;
     h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
@@ -338,10 +415,13 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, (char**)&h->dl3T, Ba * 64 * ts));
     CK(alloc_dev(h, &h->loss_t, Ba));
     CK(alloc_dev(h, &h->loss_dev, (size_t)1));
-    CK(alloc_dev(h, &h->rec, (size_t)h->F * h->N2max));
-    CK(alloc_dev(h, &h->part, (size_t)h->F * (h->N2max / 16) * 2 * SLOT));
-    CK(alloc_dev(h, &h->owners, (size_t)h->F * (h->N2max / 16)));
-    CK(alloc_dev(h, &h->owner_cnt, (size_t)1));
+    for (auto& sl : h->slot) {
+        CK(alloc_dev(h, &sl.rec, (size_t)h->F * h->N2max));
+        CK(alloc_dev(h, &sl.part, (size_t)h->F * (h->N2max / 16) * 2 * SLOT));
+        CK(alloc_dev(h, &sl.owners, (size_t)h->F * (h->N2max / 16)));
+        CK(alloc_dev(h, &sl.owner_cnt, (size_t)1));
+    }
+    h->key64 = !((unsigned long long)h->cfg.max_batch <= 4096ull);   // refined when the table is set
     CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
     CK(alloc_dev(h, &h->err_flag, (size_t)1));
     CK(alloc_dev(h, &h->st_ids, (size_t)h->Bmax * h->F));
@@ -365,16 +445,15 @@ int fnn_destroy(fnn_handle* h)
     if (!h) return FNN_ERR_ARG;
     hipSetDevice(h->dev);
     if (h->st) hipStreamSynchronize(h->st);
-    if (h->st_side) hipStreamSynchronize(h->st_side);
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
-                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->rec, h->part, h->owners, h->owner_cnt, h->cpow_dev, h->err_flag,
+                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag,
                     h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
     for (void* p : ptrs) if (p) hipFree(p);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
-    if (h->st_side) hipStreamDestroy(h->st_side);
+    for (auto& sl : h->slot) {
+        for (void* p : {(void*)sl.rec, (void*)sl.part, (void*)sl.owners, (void*)sl.owner_cnt}) if (p) hipFree(p);
+    }
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
@@ -393,7 +472,6 @@ int fnn_sync(fnn_handle* h)
 {
     if (!h) return FNN_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->dev));
-    HIPCHK(h, hipStreamSynchronize(h->st_side));
     return check_async(h);
 }
 
@@ -425,6 +503,8 @@ int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows, const int32_
     HIPCHK(h, hipStreamSynchronize(h->st));
     if (tmp) hipFree(tmp);
     h->n_rows = n_rows; h->w0 = w0;
+    h->key64 = (unsigned long long)n_rows * SORT_N > 0xFFFFFFFFull;     // else 32-bit (row << 12 | t) keys
+    h->sorted_ids = nullptr; h->next_ids = nullptr;
     return FNN_OK;
 }
 
@@ -568,8 +648,9 @@ int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memki
     return FNN_OK;
 }
 
-int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* mask1,
-                   const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind)
+static int step_impl(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* mask1,
+                     const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind,
+                     bool inline_update)
 {
     int rc = check_ready(h, B);
     if (rc != FNN_OK) return rc;
@@ -589,9 +670,16 @@ int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, con
         ids_d = h->st_ids; y_d = h->st_y; m1 = h->st_m1; m2 = h->st_m2;
         if (p_out) p_d = h->st_p;
         if (gx_out) gx_d = h->st_x;
+        h->sorted_ids = nullptr; h->next_ids = nullptr;     // staging buffers are reused: no carried grouping
     }
-    rc = h->bf16 ? run_step<bf16_t>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d)
-                 : run_step<float>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d);
+    const bool fast = h->fused && mlp_shape_ok(h) && B <= SORT_N;
+    h->update_pending = !(fast && inline_update);
+    if (fast)
+        rc = h->bf16 ? run_step_fast<bf16_t>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update)
+                     : run_step_fast<float>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update);
+    else
+        rc = h->bf16 ? run_step<bf16_t>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d)
+                     : run_step<float>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d);
     if (rc != FNN_OK) return rc;
     if (memkind == FNN_MEM_HOST) {
         if (p_out) HIPCHK(h, hipMemcpyAsync(p_out, p_d, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
@@ -599,6 +687,21 @@ int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, con
         if (p_out || gx_out) HIPCHK(h, hipStreamSynchronize(h->st));
     }
     h->in_step = true; h->step_B = B;
+    return FNN_OK;
+}
+
+int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* mask1,
+                   const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind)
+{
+    return step_impl(h, ids, y, B, mask1, mask2, b_size, p_out, gx_out, memkind, false);
+}
+
+int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B)
+{
+    int rc = check_ready(h, B);
+    if (rc != FNN_OK) return rc;
+    if (!ids) FAIL(h, FNN_ERR_ARG, "ids null");
+    h->next_ids = ids; h->next_B = B;       // grouped by the next step's first launch
     return FNN_OK;
 }
 
@@ -614,7 +717,7 @@ int fnn_step_end(fnn_handle* h, float* loss_sum_out)
     if (!h) return FNN_ERR_ARG;
     if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_end without fnn_step_begin");
     HIPCHK(h, hipSetDevice(h->dev));
-    {
+    if (h->update_pending) {
         ProfScope ps(h, "update", h->st);
         if (h->bf16) launch_update<bf16_t>(h, h->bucket, h->cfg.lr); else launch_update<float>(h, h->bucket, h->cfg.lr);
     }
@@ -636,7 +739,7 @@ int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B, con
                    const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind,
                    float* loss_sum_out)
 {
-    int rc = fnn_step_begin(h, ids, y, B, mask1, mask2, b_size, p_out, gx_out, memkind);
+    int rc = step_impl(h, ids, y, B, mask1, mask2, b_size, p_out, gx_out, memkind, true);
     if (rc != FNN_OK) return rc;
     return fnn_step_end(h, loss_sum_out);
 }
@@ -668,7 +771,6 @@ int fnn_prof_enable(fnn_handle* h, int on) { if (!h) return FNN_ERR_ARG; h->prof
 static int prof_collect(fnn_handle* h)
 {
     HIPCHK(h, hipStreamSynchronize(h->st));
-    HIPCHK(h, hipStreamSynchronize(h->st_side));
     for (auto& kv : h->prof_slots) {
         for (auto& p : kv.second.ev) {
             float ms = 0.f;

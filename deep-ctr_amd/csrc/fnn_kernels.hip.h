@@ -255,17 +255,24 @@ struct WgradProb { const void* A; const void* B; float* out; int mt, nt, ldo; };
 struct WgradArgs { WgradProb p[3]; int ldT, klen; size_t zstride; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a)
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int KS = Traits<T>::KS;
-    int b = blockIdx.x, pi = 0;
-    while (pi < 2 && b >= a.p[pi].mt * a.p[pi].nt) { b -= a.p[pi].mt * a.p[pi].nt; ++pi; }
-    const WgradProb pr = a.p[pi];
+    // pick the product by scalar selects (a runtime index into the argument struct would spill it)
+    const int n0 = a.p[0].mt * a.p[0].nt, n1 = a.p[1].mt * a.p[1].nt;
+    const int pi = bx < n0 ? 0 : (bx < n0 + n1 ? 1 : 2);
+    const int b = bx - (pi == 0 ? 0 : (pi == 1 ? n0 : n0 + n1));
+    WgradProb pr;
+    pr.A = pi == 0 ? a.p[0].A : (pi == 1 ? a.p[1].A : a.p[2].A);
+    pr.B = pi == 0 ? a.p[0].B : (pi == 1 ? a.p[1].B : a.p[2].B);
+    pr.out = pi == 0 ? a.p[0].out : (pi == 1 ? a.p[1].out : a.p[2].out);
+    pr.nt = pi == 0 ? a.p[0].nt : (pi == 1 ? a.p[1].nt : a.p[2].nt);
+    pr.ldo = pi == 0 ? a.p[0].ldo : (pi == 1 ? a.p[1].ldo : a.p[2].ldo);
     const int bm = b / pr.nt, bn = b % pr.nt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rt = bm * 4 + wave, ct0 = bn * 4;
-    const int nkt_all = a.ldT / KS, kt0 = blockIdx.y * (a.klen / KS), nkt = a.klen / KS;
+    const int nkt_all = a.ldT / KS, kt0 = by * (a.klen / KS), nkt = a.klen / KS;
     const T* A = static_cast<const T*>(pr.A);
     const T* B = static_cast<const T*>(pr.B);
     f32x4 acc[4];
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a)
             mma(acc[n], af, bf);
         }
     }
-    float* o = pr.out + (size_t)blockIdx.y * a.zstride;
+    float* o = pr.out + (size_t)by * a.zstride;
     const int r0 = rt * 16 + 4 * (lane >> 4);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -289,6 +296,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a)
         for (int r = 0; r < 4; ++r) o[(size_t)(r0 + r) * pr.ldo + col] = acc[n][r];
     }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) { wgrad_body<T>(a, blockIdx.x, blockIdx.y); }
 
 // ------------------------------------------------------------------------------------------
 // Fused MLP strip kernel: A3 gather -> A4 forward -> loss -> A5 backward-data for 16 examples per
@@ -310,7 +320,7 @@ template <typename T> struct MlpArgs {
 };
 
 template <typename T, int C1, int C2, int CX>
-__global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
+__device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, unsigned char* smem)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
@@ -318,15 +328,18 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
     constexpr int PAD = 16 / (int)sizeof(T);
     constexpr int LX = K1p + PAD, L1 = H1p + PAD, L2 = H2p + PAD;
     constexpr int LXM = LX > L1 ? LX : L1;
-    extern __shared__ __align__(16) unsigned char smem[];
     T* sx = reinterpret_cast<T*>(smem);          // [16][LXM]  x' tile, later delta1 (stride L1)
     T* sd1 = sx + 16 * LXM;                      // [16][L1]   d1
     T* sdl2 = sd1 + 16 * L1;                     // [16][L2]   delta2
     float* sz = reinterpret_cast<float*>(sdl2 + 16 * L2);   // [4][16]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int t0 = blockIdx.x * 16;
+    const int t0 = blk * 16;
     const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
+    // Every workgroup streams the same weights; workgroups that share an XCD (blockIdx % 8 under
+    // round-robin dispatch -- a speed assumption only) start their k walk at different offsets so
+    // that they do not hit the same L2 channel in lock step.
+    const int rot = blk >> 3;
 
     // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96)
     for (int e = tid; e < 16 * F; e += 256) {
@@ -371,7 +384,8 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sx + lr * LX + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < K1p / KS; ++kk) {
+        for (int k0 = 0; k0 < K1p / KS; ++k0) {
+            const int kk = (k0 + rot) % (K1p / KS);
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
@@ -405,7 +419,8 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
         for (int i = 0; i < C2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sd1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H1p / KS; ++kk) {
+        for (int k0 = 0; k0 < H1p / KS; ++k0) {
+            const int kk = (k0 + rot) % (H1p / KS);
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C2; ++i) {
@@ -483,7 +498,8 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl2 + lr * L2 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H2p / KS; ++kk) {
+        for (int k0 = 0; k0 < H2p / KS; ++k0) {
+            const int kk = (k0 + rot) % (H2p / KS);
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
@@ -515,7 +531,8 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
         for (int i = 0; i < CX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H1p / KS; ++kk) {
+        for (int k0 = 0; k0 < H1p / KS; ++k0) {
+            const int kk = (k0 + rot) % (H1p / KS);
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < CX; ++i) {
@@ -530,6 +547,13 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
             for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
         }
     }
+}
+
+template <typename T, int C1, int C2, int CX>
+__global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    mlp_body<T, C1, C2, CX>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -772,14 +796,18 @@ __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_scat1(const int4* __restrict__ rec, int N2, int F, int K,
-                                               const float* __restrict__ gxp, int K1p,
-                                               const double* __restrict__ cpow, double lr,
-                                               float* __restrict__ table16, double* __restrict__ part,
-                                               int* __restrict__ owner_cnt, int4* __restrict__ owners)
+struct ScatArgs {
+    const int4* rec; int N2, F, K; const float* gxp; int K1p; const double* cpow; double lr;
+    float* table16; double* part; int* owner_cnt; int4* owners;
+};
+__device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
 {
+    const int4* __restrict__ rec = sa.rec; const int N2 = sa.N2, F = sa.F, K = sa.K, K1p = sa.K1p;
+    const float* __restrict__ gxp = sa.gxp; const double* __restrict__ cpow = sa.cpow; const double lr = sa.lr;
+    float* __restrict__ table16 = sa.table16; double* __restrict__ part = sa.part;
+    int* __restrict__ owner_cnt = sa.owner_cnt; int4* __restrict__ owners = sa.owners;
     const int l = threadIdx.x & 15;                       // slot of the row
-    const int G = (blockIdx.x * 256 + threadIdx.x) >> 4;  // chunk of 16 sorted entries
+    const int G = (blk * 256 + threadIdx.x) >> 4;         // chunk of 16 sorted entries
     const int NQ = N2 >> 4;
     if (G >= F * NQ) return;
     const int f = G / NQ, q = G % NQ, base = q * 16;
@@ -818,17 +846,17 @@ __global__ __launch_bounds__(256) void k_scat1(const int4* __restrict__ rec, int
     }
 }
 
-__global__ __launch_bounds__(256) void k_scat2(const int* __restrict__ owner_cnt,
-                                               const int4* __restrict__ owners, int N2, int K,
-                                               const double* __restrict__ part,
-                                               const double* __restrict__ cpow, double lr,
-                                               float* __restrict__ table16)
+__global__ __launch_bounds__(256) void k_scat1(const ScatArgs sa) { scat1_body(sa, blockIdx.x); }
+
+__device__ __forceinline__ void scat2_body(const ScatArgs& sa, const int blk, const int nblk, double (*s_sum)[16])
 {
-    __shared__ double s_sum[16][16];
-    const int n = *owner_cnt;
+    const int4* __restrict__ owners = sa.owners; const int N2 = sa.N2, K = sa.K;
+    const double* __restrict__ part = sa.part; const double* __restrict__ cpow = sa.cpow; const double lr = sa.lr;
+    float* __restrict__ table16 = sa.table16;
+    const int n = *sa.owner_cnt;
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int NQ = N2 >> 4;
-    for (int o = blockIdx.x; o < n; o += gridDim.x) {
+    for (int o = blk; o < n; o += nblk) {
         const int4 ow = owners[o];                         // {f, s, e, row}
         const int q0 = ow.y >> 4, q1 = (ow.z - 1) >> 4;
         double sum = 0.0;
@@ -845,6 +873,12 @@ __global__ __launch_bounds__(256) void k_scat2(const int* __restrict__ owner_cnt
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_scat2(const ScatArgs sa)
+{
+    __shared__ double s_sum[16][16];
+    scat2_body(sa, blockIdx.x, gridDim.x, s_sum);
 }
 
 // helpers for fnn_set_table / fnn_get_table / fnn_get_rows

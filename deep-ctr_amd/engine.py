@@ -174,6 +174,13 @@ class FNNEngine(object):
             out['gx'] = gx
         return out
 
+    def prefetch_ids(self, ids_t):
+        """Scheduling hint: start grouping the ids of an upcoming batch (a device int32 tensor that
+        will be passed unchanged to train_step / step_begin)."""
+        assert ids_t.is_cuda and ids_t.dtype == self._torch.int32 and ids_t.is_contiguous()
+        self._enter()
+        self._ck(self.lib.fnn_prefetch_ids(self.h, ids_t.data_ptr(), ids_t.shape[0]))
+
     def step_begin(self, ids, y, mask1, mask2, b_size=0):
         """Data-parallel half step: everything but the dense SGD.  Returns the flat dense-gradient
         bucket as a torch tensor aliasing the library's buffer (all-reduce it, then step_end())."""

@@ -112,6 +112,15 @@ int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B,
                    const uint8_t* mask1, const uint8_t* mask2, int b_size,
                    float* p_out, float* gx_out, int memkind, float* loss_sum_out);
 
+/* Optional: hand the ids of an UPCOMING training batch to the library (DEVICE pointer, same
+ * pointer and B as the later fnn_train_step / fnn_step_begin call).  The sparse-row update first
+ * groups a batch's (row, example) pairs by row -- the device-side counterpart of the reference
+ * walking `for feat in ft` in example order (python/FNN_wnzh.py:300-306) -- and that grouping
+ * depends on the ids only, so it can run while the previous step still computes.  Purely a
+ * scheduling hint: results are identical with or without it.  The ids must not change between
+ * this call and the step that consumes them. */
+int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B);
+
 /* The same pass split for data parallelism: _begin runs everything except the
  * dense SGD and leaves the dense gradients (sum over this rank's examples, the
  * reference loss being a batch SUM, python/FNN_wnzh.py:173) in one flat f32

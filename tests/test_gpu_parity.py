@@ -141,6 +141,30 @@ def test_layer_by_layer_path_matches_strip_kernel(built, prec, monkeypatch):
         np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=tol * 10, atol=tol)
 
 
+def test_prefetch_ids_changes_nothing(built):
+    """fnn_prefetch_ids is a scheduling hint: with or without it the state after several steps is
+    bitwise identical (and so is a run where the hint named a batch that never came)."""
+    import torch
+    rows, fo, ids, y, p, r1, r2 = make_problem(1200, seed=31, dup_col=3)
+    res = []
+    for mode in ('none', 'next', 'wrong'):
+        eng = make_engine(rows, fo, p, prec='bf16', lr=0.01)
+        dev_ids = [torch.as_tensor(ids[j * 300:(j + 1) * 300]).to(eng.device).contiguous() for j in range(4)]
+        for j in range(4):
+            if mode == 'next' and j + 1 < 4:
+                eng.prefetch_ids(dev_ids[j + 1])
+            if mode == 'wrong':
+                eng.prefetch_ids(dev_ids[(j + 2) % 4])
+            eng.train_step(dev_ids[j], y[j * 300:(j + 1) * 300], r1, r2, want_loss=False)
+        eng.sync()
+        res.append((eng.get_table(), eng.get_dense()))
+        eng.close()
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0])
+        for k in ('w1', 'w2', 'w3', 'b1', 'b2'):
+            assert np.array_equal(res[0][1][k], other[1][k])
+
+
 def test_train_step_f32_global_batch_decay(built):
     """Data-parallel callers pass the GLOBAL batch length for the decay constant (:304)."""
     rows, fo, ids, y, p, r1, r2 = make_problem(50, seed=3)
