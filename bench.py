@@ -108,8 +108,9 @@ def main():
     bucket = eng.grad_bucket()
 
     def step(i):
-        nb = (i + 1) % NB                                 # hand the NEXT batch's ids to the sort early
-        lib.fnn_prefetch_ids(h, ids.data_ptr() + nb * B * F * 4, B)
+        if not os.environ.get('FNN_BENCH_NOPREFETCH'):
+            nb = (i + 1) % NB                             # hand the NEXT batch's ids to the library early
+            lib.fnn_prefetch_ids(h, ids.data_ptr() + nb * B * F * 4, B)
         b = i % NB
         a = (h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, m1.data_ptr() + b * H1,
              m2.data_ptr() + b * H2, gB)

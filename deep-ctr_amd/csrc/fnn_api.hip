@@ -63,6 +63,7 @@ struct fnn_handle {
     double* cpow_dev = nullptr;
     std::vector<double> cpow_host; double cpow_c = -1.0; int cpow_n = 0;
     int* err_flag = nullptr;
+    uint8_t* ones_u8 = nullptr;         // all-ones dropout rows for predict
     // host-pointer staging
     int32_t* st_ids = nullptr; float* st_y = nullptr; uint8_t* st_m1 = nullptr; uint8_t* st_m2 = nullptr;
     float* st_p = nullptr; float* st_x = nullptr;
@@ -169,9 +170,10 @@ ScatArgs make_scat_args(fnn_handle* h, const fnn_handle::SortSlot& sl, int N2) {
 }
 template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids, const float* y, int B,
                                                 const uint8_t* m1, const uint8_t* m2, bool train, float* p_out) {
-    return MlpArgs<T>{ids, y, B, h->F, h->K, h->table16, h->n_rows, h->w0,
+    return MlpArgs<T>{ids, y ? y : h->loss_t, B, h->F, h->K, h->table16, h->n_rows, h->w0,
                       (const T*)h->w1, (const T*)h->w1t, (const T*)h->w2, (const T*)h->w2t, h->master + h->nw12,
-                      m1, m2, h->cfg.act, train ? ACT_TANH : h->cfg.act, h->H1, h->H2, train ? 1 : 0,
+                      m1 ? m1 : h->ones_u8, m2 ? m2 : h->ones_u8, h->cfg.act, train ? ACT_TANH : h->cfg.act,
+                      h->H1, h->H2, train ? 1 : 0,
                       (T*)h->xpT, (T*)h->d1T, (T*)h->d2T, (T*)h->dl1T, (T*)h->dl2T, (T*)h->dl3T, h->ldT,
                       h->gxp, p_out, h->loss_t, h->err_flag};
 }
@@ -424,6 +426,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->key64 = !((unsigned long long)h->cfg.max_batch <= 4096ull);   // refined when the table is set
     CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
     CK(alloc_dev(h, &h->err_flag, (size_t)1));
+    CK(alloc_dev(h, &h->ones_u8, (size_t)(h->H1p + h->H2p), false));
+    HK(hipMemsetAsync(h->ones_u8, 1, (size_t)(h->H1p + h->H2p), h->st));
     CK(alloc_dev(h, &h->st_ids, (size_t)h->Bmax * h->F));
     CK(alloc_dev(h, &h->st_y, (size_t)h->Bmax));
     CK(alloc_dev(h, &h->st_m1, (size_t)h->H1p)); CK(alloc_dev(h, &h->st_m2, (size_t)h->H2p));
@@ -448,7 +452,7 @@ int fnn_destroy(fnn_handle* h)
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
-                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag,
+                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag, h->ones_u8,
                     h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : h->slot) {

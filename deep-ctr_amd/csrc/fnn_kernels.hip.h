@@ -84,6 +84,18 @@ __device__ inline float4 load4(const bf16_t* p) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
+// tanh for the bf16 mode: 1 - 2/(exp(2z)+1) with the hardware exp (abs. error ~1e-7, far below
+// bf16's 2^-9); the f32 parity mode keeps libm's tanhf.
+template <typename T> __device__ inline float tanh_t(float z) { return tanhf(z); }
+template <> __device__ inline float tanh_t<bf16_t>(float z) {
+    const float e = __expf(2.0f * fminf(fmaxf(z, -15.f), 15.f));
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+template <typename T> __device__ inline float act_fn_t(float z, int act) {
+    if (act == ACT_TANH) return tanh_t<T>(z);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-z));
+    return z;
+}
 __device__ inline float act_fn(float z, int act) {
     if (act == ACT_TANH) return tanhf(z);
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-z));
@@ -336,26 +348,54 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int t0 = blk * 16;
     const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
-    // Every workgroup streams the same weights; workgroups that share an XCD (blockIdx % 8 under
-    // round-robin dispatch -- a speed assumption only) start their k walk at different offsets so
-    // that they do not hit the same L2 channel in lock step.
-    const int rot = blk >> 3;
 
-    // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96)
+    // small per-column operands first, so that no later load has to wait behind a store
+    float m1v[C1], m2v[C2], w3v[C2];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        const int col = (wave * C1 + i) * 16 + lr;
+        const float mv = (float)a.m1[col < a.H1 ? col : 0];      // m1 is never null (predict: ones)
+        m1v[i] = (col < a.H1) ? mv : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < C2; ++i) {
+        const int col = (wave * C2 + i) * 16 + lr;
+        const float mv = (float)a.m2[col < a.H2 ? col : 0];
+        m2v[i] = (col < a.H2) ? mv : 0.0f;
+        w3v[i] = a.w3p[col];
+    }
+
+    float yv[4];                                   // labels of this lane's 4 rows (y is never null)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int t = t0 + 4 * lq + r; yv[r] = a.y[t < B ? t : B - 1]; }
+
+    // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96).
+    // All ids first, then all rows: two dependent round trips for the whole strip.
     for (int e = tid; e < 16 * F; e += 256) {
         const int q = e & 3, f = (e >> 2) % F, tq = (e >> 2) / F;
+        int64_t id[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + 4 * tq + i;
+            id[i] = a.ids[(size_t)(t < B ? t : B - 1) * F + f];
+        }
+        bool bad = false;
+        float4 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + 4 * tq + i;
+            if (t >= B) id[i] = -1;
+            if (id[i] < -1 || id[i] >= a.n_rows) { bad = true; id[i] = -1; }
+            r[i] = *reinterpret_cast<const float4*>(a.table16 + (size_t)(id[i] < 0 ? 0 : id[i]) * SLOT + 4 * q);
+        }
+        if (bad) atomicOr(a.err, 1);
         float v[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = t0 + 4 * tq + i;
-            int64_t id = -1;
-            if (t < B) {
-                id = a.ids[(size_t)t * F + f];
-                if (id < -1 || id >= a.n_rows) { atomicOr(a.err, 1); id = -1; }
-            }
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id >= 0) r = *reinterpret_cast<const float4*>(a.table16 + (size_t)id * SLOT + 4 * q);
-            v[i][0] = r.x; v[i][1] = r.y; v[i][2] = r.z; v[i][3] = r.w;
+            const bool live = id[i] >= 0;
+            v[i][0] = live ? r[i].x : 0.f; v[i][1] = live ? r[i].y : 0.f;
+            v[i][2] = live ? r[i].z : 0.f; v[i][3] = live ? r[i].w : 0.f;
             if (t < B && q == (K >> 2)) {
                 if (f == 0) v[i][K & 3] = a.w0;
                 if (f == 1) v[i][K & 3] = 1.0f;
@@ -384,8 +424,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sx + lr * LX + lq * EPL;
 #pragma unroll
-        for (int k0 = 0; k0 < K1p / KS; ++k0) {
-            const int kk = (k0 + rot) % (K1p / KS);
+        for (int kk = 0; kk < K1p / KS; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
@@ -396,12 +435,11 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
-            float m = 0.f;
-            if (col < a.H1) m = a.m1 ? (float)a.m1[col] : 1.0f;
+            const float m = m1v[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * lq + r;
-                const float x = (col < a.H1) ? act_fn(acc[i][r], a.act1) * m : (col == a.H1 ? 1.0f : 0.0f);
+                const float x = (col < a.H1) ? act_fn_t<T>(acc[i][r], a.act1) * m : (col == a.H1 ? 1.0f : 0.0f);
                 const float v = (t0 + row < B) ? x : 0.0f;
                 d1v[i][r] = v;
                 sd1[row * L1 + col] = (T)v;
@@ -419,8 +457,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int i = 0; i < C2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sd1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int k0 = 0; k0 < H1p / KS; ++k0) {
-            const int kk = (k0 + rot) % (H1p / KS);
+        for (int kk = 0; kk < H1p / KS; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C2; ++i) {
@@ -431,13 +468,11 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < C2; ++i) {
             const int col = (wave * C2 + i) * 16 + lr;
-            float m = 0.f;
-            if (col < a.H2) m = a.m2 ? (float)a.m2[col] : 1.0f;
-            const float w3 = a.w3p[col];
+            const float m = m2v[i], w3 = w3v[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * lq + r;
-                const float x = (col < a.H2) ? act_fn(acc[i][r], a.act2) * m : (col == a.H2 ? 1.0f : 0.0f);
+                const float x = (col < a.H2) ? act_fn_t<T>(acc[i][r], a.act2) * m : (col == a.H2 ? 1.0f : 0.0f);
                 const float v = (t0 + row < B) ? x : 0.0f;
                 d2v[i][r] = v;
                 zp[r] += v * w3;
@@ -462,7 +497,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (t < B) {
             if (a.p_out && wave == 0 && lr == 0) a.p_out[t] = p;
             if (a.train) {
-                const float yy = a.y[t];
+                const float yy = yv[r];
                 d3[r] = p - yy;
                 ls[r] = fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))) - yy * z;   // = -y log p - (1-y) log(1-p)
             }
@@ -477,9 +512,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
     for (int i = 0; i < C2; ++i) {
         const int col = (wave * C2 + i) * 16 + lr;
-        float m = 0.f;
-        if (col < a.H2) m = a.m2 ? (float)a.m2[col] : 1.0f;
-        const float w3m = a.w3p[col] * m;
+        const float w3m = w3v[i] * m2v[i];
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -498,8 +531,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl2 + lr * L2 + lq * EPL;
 #pragma unroll
-        for (int k0 = 0; k0 < H2p / KS; ++k0) {
-            const int kk = (k0 + rot) % (H2p / KS);
+        for (int kk = 0; kk < H2p / KS; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
@@ -510,8 +542,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
-            float m = 0.f;
-            if (col < a.H1) m = a.m1 ? (float)a.m1[col] : 1.0f;
+            const float m = m1v[i];
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -531,8 +562,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int i = 0; i < CX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int k0 = 0; k0 < H1p / KS; ++k0) {
-            const int kk = (k0 + rot) % (H1p / KS);
+        for (int kk = 0; kk < H1p / KS; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < CX; ++i) {
