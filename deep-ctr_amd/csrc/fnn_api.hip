@@ -142,7 +142,8 @@ void launch_gemm(hipStream_t s, const T* A, int lda, const T* Bft, int M, int N,
 template <typename T> void launch_update(fnn_handle* h, const float* bucket, float lr) {
     const size_t n = h->nw;
     hipLaunchKernelGGL((k_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->master,
-                       bucket, lr, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t);
+                       bucket, lr, h->cfg.lambda1, h->cfg.reg_all, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t,
+                       (T*)h->w2, (T*)h->w2t);
 }
 
 // the strip kernel is instantiated for the padded shapes in use; anything else takes the

@@ -666,8 +666,8 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
 }
 
 // ------------------------------------------------------------------------------------------
-// Dense gradient bucket: sum the split-K slabs in a fixed order, add the L2 term 2*lambda1*theta
-// (python/FNN_wnzh.py:173; SNN: all six tensors); the last block sums the per-example losses.
+// Dense gradient bucket: sum the split-K slabs in a fixed order (the per-example part of the
+// gradient, which is what data parallelism all-reduces); the last block sums the per-example losses.
 // Slab z = [W1p grads n1 | W2p grads n2 | gw3p as column 0 of an [H2p][64] tile].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, int splitk,
@@ -695,22 +695,25 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, 
     float g = 0.f;
 #pragma unroll 8
     for (int z = 0; z < splitk; ++z) g += slab[(size_t)z * nslab + src];
-    if (reg_all || i >= nw12) g += 2.0f * lambda1 * master[i];
-    bucket[i] = g;
+    bucket[i] = g;       // data term only: the L2 term is added where theta is updated (k_update)
 }
 
-// theta <- theta - lr * g  (python/FNN_wnzh.py:179-182) on the f32 masters, then refresh the
+// theta <- theta - lr * (g + L2 term)  (python/FNN_wnzh.py:173,179-182) on the f32 masters, then refresh the
 // compute-precision shadows in both orientations, fragment-tiled (ft_off).
 template <typename T>
 __global__ void k_update(float* __restrict__ master, const float* __restrict__ bucket, float lr,
-                         int K1p, int H1p, int H2p, T* __restrict__ w1, T* __restrict__ w1t,
-                         T* __restrict__ w2, T* __restrict__ w2t)
+                         float lambda1, int reg_all, int K1p, int H1p, int H2p, T* __restrict__ w1,
+                         T* __restrict__ w1t, T* __restrict__ w2, T* __restrict__ w2t)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n1 = (size_t)K1p * H1p, n2 = (size_t)H1p * H2p;
     if (i >= n1 + n2 + H2p) return;
     float w = master[i];
-    if (bucket) { w -= lr * bucket[i]; master[i] = w; }
+    if (bucket) {      // + L2 term 2*lambda1*theta on w3,b3 (python/FNN_wnzh.py:173) or on all six (SNN)
+        float g = bucket[i];
+        if (reg_all || i >= n1 + n2) g += 2.0f * lambda1 * w;
+        w -= lr * g; master[i] = w;
+    }
     if (i < n1) {           // W1p[r = x' slot][c = h1 unit]
         const int r = (int)(i / H1p), c = (int)(i % H1p);
         w1t[ft_off<T>(c, r, K1p)] = (T)w;      // forward:  output column c, contraction over r

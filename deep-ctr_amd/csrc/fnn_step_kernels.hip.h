@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void k_step3(const TailArgs ta, const ScatArgs
 #pragma unroll 8
     for (int z = 0; z < ta.splitk; ++z) g += ta.slab[(size_t)z * ta.nslab + src];
     float w = ta.master[i];
-    if (ta.reg_all || i >= ta.nw12) g += 2.0f * ta.lambda1 * w;
-    ta.bucket[i] = g;
+    ta.bucket[i] = g;                 // data term only (what data parallelism all-reduces)
     if (UPDATE) {
+        if (ta.reg_all || i >= ta.nw12) g += 2.0f * ta.lambda1 * w;     // L2 term (:173)
         w -= ta.lr * g;
         ta.master[i] = w;
         const size_t n1 = (size_t)ta.K1p * ta.H1p, n2 = (size_t)ta.H1p * ta.H2p;

@@ -141,6 +141,46 @@ def test_layer_by_layer_path_matches_strip_kernel(built, prec, monkeypatch):
         np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=tol * 10, atol=tol)
 
 
+def test_virtual_two_rank_dp_equals_single_gpu_dense(built):
+    """Two engines stand for two ranks: each runs fnn_step_begin on its contiguous half with the
+    GLOBAL batch length, the flat buckets are summed (what the RCCL all-reduce does) and
+    fnn_step_end applies them.  Dense tensors must equal the single-engine full-batch step, also
+    with an L2 term (which must not be all-reduced), and each rank's table holds its shard's rows."""
+    import torch
+    rows, fo, ids, y, p, r1, r2 = make_problem(512, seed=41, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.05, lamfm=0.1)
+    full = make_engine(rows, fo, p, **kw)
+    full.train_step(ids, y, r1, r2)
+    ref_dense, ref_rows = full.get_dense(), full.get_table()
+    full.close()
+    ranks = [make_engine(rows, fo, p, **kw) for _ in range(2)]
+    halves = [slice(0, 256), slice(256, 512)]
+    buckets = [e.step_begin(ids[h], y[h], r1, r2, b_size=512) for e, h in zip(ranks, halves)]
+    for e in ranks:
+        e.sync()
+    tot = buckets[0] + buckets[1]
+    for e, b in zip(ranks, buckets):
+        b.copy_(tot)
+    torch.cuda.synchronize()
+    for e in ranks:
+        e.step_end()
+        e.sync()
+    for e in ranks:
+        d = e.get_dense()
+        for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+            scale = np.abs(d[k] - p[k].astype(np.float32)).max() + 1e-12
+            assert np.abs(d[k] - ref_dense[k]).max() <= 2e-4 * scale + 1e-7, k
+        assert abs(d['b3'] - ref_dense['b3']) < 1e-6
+    # rows touched by one half only must match the full-batch result on the rank that owns that half
+    t0, t1 = set(np.unique(ids[halves[0]])), set(np.unique(ids[halves[1]]))
+    only0 = np.array(sorted(t0 - t1)); only1 = np.array(sorted(t1 - t0))
+    np.testing.assert_allclose(ranks[0].get_rows(only0), ref_rows[only0], rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(ranks[1].get_rows(only1), ref_rows[only1], rtol=1e-5, atol=2e-7)
+    assert np.array_equal(ranks[0].get_rows(only1), rows[only1])       # never touched on rank 0
+    for e in ranks:
+        e.close()
+
+
 def test_prefetch_ids_changes_nothing(built):
     """fnn_prefetch_ids is a scheduling hint: with or without it the state after several steps is
     bitwise identical (and so is a run where the hint named a batch that never came)."""
