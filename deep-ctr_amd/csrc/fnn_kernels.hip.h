@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fnn {
 
@@ -78,6 +79,12 @@ __device__ inline void store4(bf16_t* p, float a, float b, float c, float d) {
     bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
     *reinterpret_cast<bf16x4*>(p) = v;
 }
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains every global
+// load and store in flight (s_waitcnt vmcnt(0)), which would serialise the strip kernel's
+// weight prefetch and its activation stores behind each phase barrier; the waves of a strip
+// exchange data through LDS alone, so lgkmcnt(0) + s_barrier is the ordering they need.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline float4 load4(const bf16_t* p) {
     bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
@@ -89,11 +96,37 @@ __device__ inline float4 load4(const bf16_t* p) {
 template <typename T> __device__ inline float tanh_t(float z) { return tanhf(z); }
 template <> __device__ inline float tanh_t<bf16_t>(float z) {
     const float e = __expf(2.0f * fminf(fmaxf(z, -15.f), 15.f));
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);     // v_exp + v_rcp, no IEEE divide
 }
+// logistic function: hardware exp + reciprocal (rel. error ~1e-7; z clamped so exp stays finite)
+__device__ inline float sigmoid_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-fminf(fmaxf(z, -80.f), 80.f)));
+}
+// Branch-free activations for the strip kernel.  tanh(z) = 2*sigmoid(2z) - 1, so one hardware
+// exp + reciprocal serves tanh and sigmoid alike: act(z) = a * 1/(1 + exp(-k z)) + b, with
+// (k, a, b) = (2, 2, -1) for tanh and (1, 1, 0) for sigmoid; linear bypasses it with a select.
+// The derivative in terms of the output d is the polynomial c0 + c1 d + c2 d^2:
+// tanh 1 - d^2, sigmoid d - d^2, linear 1.  (Abs. error of the forward form ~2e-7.)
+struct ActCoef { float k, a, b, c0, c1, c2; bool lin; };
+__device__ inline ActCoef act_coef(int act) {
+    ActCoef c;
+    c.lin = act == ACT_LINEAR;
+    c.k = act == ACT_TANH ? 2.0f : 1.0f;
+    c.a = act == ACT_TANH ? 2.0f : 1.0f;
+    c.b = act == ACT_TANH ? -1.0f : 0.0f;
+    c.c0 = act == ACT_SIGMOID ? 0.0f : 1.0f;
+    c.c1 = act == ACT_SIGMOID ? 1.0f : 0.0f;
+    c.c2 = act == ACT_LINEAR ? 0.0f : -1.0f;
+    return c;
+}
+__device__ inline float act_apply(const ActCoef& c, float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-c.k * z));
+    return c.lin ? z : fmaf(c.a, s, c.b);
+}
+__device__ inline float dact_apply(const ActCoef& c, float d) { return fmaf(fmaf(c.c2, d, c.c1), d, c.c0); }
 template <typename T> __device__ inline float act_fn_t(float z, int act) {
     if (act == ACT_TANH) return tanh_t<T>(z);
-    if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-z));
+    if (act == ACT_SIGMOID) return sigmoid_fast(z);
     return z;
 }
 __device__ inline float act_fn(float z, int act) {
@@ -329,7 +362,15 @@ template <typename T> struct MlpArgs {
     int act1, act2, H1, H2, train;
     T *xpT, *d1T, *d2T, *dl1T, *dl2T, *dl3T; int ldT;
     float *gxp, *p_out, *loss_t; int* err;
+#ifdef FNN_STAMPS
+    long long* dbg;                 // diagnostic build only: per-workgroup phase time stamps
+#endif
 };
+#ifdef FNN_STAMPS
+#define FNN_STAMP(i) do { if (threadIdx.x == 0) a.dbg[(size_t)blk * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FNN_STAMP(i) do { } while (0)
+#endif
 
 template <typename T, int C1, int C2, int CX>
 __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, unsigned char* smem)
@@ -348,6 +389,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int t0 = blk * 16;
     const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
+    FNN_STAMP(0);
 
     // small per-column operands first, so that no later load has to wait behind a store
     float m1v[C1], m2v[C2], w3v[C2];
@@ -365,9 +407,26 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         w3v[i] = a.w3p[col];
     }
 
+    float rv[4];                                   // 1 for rows of the batch, 0 for the padding rows
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rv[r] = (t0 + 4 * lq + r < B) ? 1.0f : 0.0f;
     float yv[4];                                   // labels of this lane's 4 rows (y is never null)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int t = t0 + 4 * lq + r; yv[r] = a.y[t < B ? t : B - 1]; }
+
+    // bf16 mode: the weight fragments of a whole phase are fetched into registers one phase AHEAD
+    // (they do not depend on the activations), so the L2 latency of the weight stream hides under
+    // the previous phase instead of being paid 8 loads at a time inside the MFMA loop.
+    constexpr bool PF = sizeof(T) == 2;
+    constexpr int NK1 = K1p / KS, NKH1 = H1p / KS, NKH2 = H2p / KS;
+    frag b1[PF ? NK1 : 1][PF ? C1 : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int kk = 0; kk < NK1; ++kk)
+#pragma unroll
+            for (int i = 0; i < C1; ++i)
+                b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
+    }
 
     // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96).
     // All ids first, then all rows: two dependent round trips for the whole strip.
@@ -414,70 +473,103 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         const int r = e / (K1p - F * SLOT), c = F * SLOT + e % (K1p - F * SLOT);
         sx[r * LX + c] = (T)0.f;
     }
-    __syncthreads();
+    lds_barrier();
+    FNN_STAMP(1);
 
     // ---- P1: d1 = act(x' W1p) * r1   (:147-155)
     float d1v[C1][4];
+    frag b2[PF ? NKH1 : 1][PF ? C2 : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int kk = 0; kk < NKH1; ++kk)
+#pragma unroll
+            for (int i = 0; i < C2; ++i)
+                b2[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, NKH1, lane));
+    }
     {
         f32x4 acc[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sx + lr * LX + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < K1p / KS; ++kk) {
+        for (int kk = 0; kk < NK1; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
-                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, K1p / KS, lane));
+                frag bf;
+                if constexpr (PF) bf = b1[kk][i];
+                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
                 mma(acc[i], af, bf);
             }
         }
+        FNN_STAMP(2);
+        // m1v is 0 outside the real columns, so act(z)*m + [col == H1] is the ones column / padding too
+        const ActCoef ac1 = act_coef(a.act1);
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
-            const float m = m1v[i];
+            const float m = m1v[i], one = (col == a.H1) ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lq + r;
-                const float x = (col < a.H1) ? act_fn_t<T>(acc[i][r], a.act1) * m : (col == a.H1 ? 1.0f : 0.0f);
-                const float v = (t0 + row < B) ? x : 0.0f;
+                const float v = fmaf(act_apply(ac1, acc[i][r]), m, one) * rv[r];
                 d1v[i][r] = v;
-                sd1[row * L1 + col] = (T)v;
+                sd1[(4 * lq + r) * L1 + col] = (T)v;
             }
-            if (a.train) store4(a.d1T + ft_off<T>(col, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
+        }
+        if (a.train) {
+#pragma unroll
+            for (int i = 0; i < C1; ++i)
+                store4(a.d1T + ft_off<T>((wave * C1 + i) * 16 + lr, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    FNN_STAMP(3);
 
     // ---- P2: d2 = act2(d1 W2p) * r2, z3 = d2 . w3p   (:164-169)
     float d2v[C2][4], zp[4] = {0.f, 0.f, 0.f, 0.f};
+    frag b3[PF ? NKH2 : 1][PF ? C1 : 1];
+    if constexpr (PF) {
+        if (a.train) {
+#pragma unroll
+            for (int kk = 0; kk < NKH2; ++kk)
+#pragma unroll
+                for (int i = 0; i < C1; ++i)
+                    b3[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, NKH2, lane));
+        }
+    }
     {
         f32x4 acc[C2];
 #pragma unroll
         for (int i = 0; i < C2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sd1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H1p / KS; ++kk) {
+        for (int kk = 0; kk < NKH1; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C2; ++i) {
-                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, H1p / KS, lane));
+                frag bf;
+                if constexpr (PF) bf = b2[kk][i];
+                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, NKH1, lane));
                 mma(acc[i], af, bf);
             }
         }
+        FNN_STAMP(4);
+        const ActCoef ac2 = act_coef(a.act2);
 #pragma unroll
         for (int i = 0; i < C2; ++i) {
             const int col = (wave * C2 + i) * 16 + lr;
-            const float m = m2v[i], w3 = w3v[i];
+            const float m = m2v[i], w3 = w3v[i], one = (col == a.H2) ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lq + r;
-                const float x = (col < a.H2) ? act_fn_t<T>(acc[i][r], a.act2) * m : (col == a.H2 ? 1.0f : 0.0f);
-                const float v = (t0 + row < B) ? x : 0.0f;
+                const float v = fmaf(act_apply(ac2, acc[i][r]), m, one) * rv[r];
                 d2v[i][r] = v;
-                zp[r] += v * w3;
+                zp[r] = fmaf(v, w3, zp[r]);
             }
-            if (a.train) store4(a.d2T + ft_off<T>(col, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
+        }
+        if (a.train) {
+#pragma unroll
+            for (int i = 0; i < C2; ++i)
+                store4(a.d2T + ft_off<T>((wave * C2 + i) * 16 + lr, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
         }
     }
 #pragma unroll
@@ -486,25 +578,25 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         zp[r] += __shfl_xor(zp[r], 4); zp[r] += __shfl_xor(zp[r], 8);
         if (lr == 0) sz[wave * 16 + 4 * lq + r] = zp[r];
     }
-    __syncthreads();
-    float d3[4], ls[4];
+    lds_barrier();
+    float d3[4], zr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r, t = t0 + row;
-        const float z = sz[row] + sz[16 + row] + sz[32 + row] + sz[48 + row];
-        const float p = 1.0f / (1.0f + expf(-z));
-        d3[r] = 0.f; ls[r] = 0.f;
-        if (t < B) {
-            if (a.p_out && wave == 0 && lr == 0) a.p_out[t] = p;
-            if (a.train) {
-                const float yy = yv[r];
-                d3[r] = p - yy;
-                ls[r] = fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))) - yy * z;   // = -y log p - (1-y) log(1-p)
-            }
-        }
+        zr[r] = sz[row] + sz[16 + row] + sz[32 + row] + sz[48 + row];
+        const float p = sigmoid_fast(zr[r]);
+        d3[r] = (a.train && t < B) ? p - yv[r] : 0.f;
+        if (a.p_out && wave == 0 && lr == 0 && t < B) a.p_out[t] = p;
     }
+    FNN_STAMP(5);
     if (!a.train) return;
-    if (wave == 0 && lr == 0) {
+    if (wave == 0 && lr == 0) {          // one lane per 4 rows writes delta3 and the per-example loss
+        float ls[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {      // -y log p - (1-y) log(1-p) = softplus(z) - y z
+            const float z = zr[r];
+            ls[r] = (t0 + 4 * lq + r < B) ? fmaxf(z, 0.f) + __logf(1.0f + __expf(-fabsf(z))) - yv[r] * z : 0.f;
+        }
         store4(a.dl3T + ft_off<T>(0, t0 + 4 * lq, ldT), d3[0], d3[1], d3[2], d3[3]);
         store4(a.loss_t + t0 + 4 * lq, ls[0], ls[1], ls[2], ls[3]);
     }
@@ -521,24 +613,37 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         }
         store4(a.dl2T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
     }
-    __syncthreads();
+    lds_barrier();
+    FNN_STAMP(6);
 
     // ---- P3: delta1 = (delta2 W2p^T) * r1 * act'(d1)
     T* sdl1 = sx;                                       // the x' tile is dead since P1
+    frag b4[PF ? NKH1 : 1][PF ? CX : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int kk = 0; kk < NKH1; ++kk)
+#pragma unroll
+            for (int i = 0; i < CX; ++i)
+                b4[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, NKH1, lane));
+    }
     {
         f32x4 acc[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl2 + lr * L2 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H2p / KS; ++kk) {
+        for (int kk = 0; kk < NKH2; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < C1; ++i) {
-                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, H2p / KS, lane));
+                frag bf;
+                if constexpr (PF) bf = b3[kk][i];
+                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, NKH2, lane));
                 mma(acc[i], af, bf);
             }
         }
+        FNN_STAMP(7);
+        const ActCoef ac1 = act_coef(a.act1);
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
@@ -546,14 +651,14 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 4 * lq + r;
-                v[r] = (t0 + row < B) ? acc[i][r] * m * dact_fn(d1v[i][r], a.act1) : 0.0f;
-                sdl1[row * L1 + col] = (T)v[r];
+                v[r] = acc[i][r] * m * dact_apply(ac1, d1v[i][r]) * rv[r];
+                sdl1[(4 * lq + r) * L1 + col] = (T)v[r];
             }
             store4(a.dl1T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    FNN_STAMP(8);
 
     // ---- P4: gx' = delta1 W1p^T   (what `train` returns first, :174,:179)
     {
@@ -562,14 +667,17 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int i = 0; i < CX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl1 + lr * L1 + lq * EPL;
 #pragma unroll
-        for (int kk = 0; kk < H1p / KS; ++kk) {
+        for (int kk = 0; kk < NKH1; ++kk) {
             const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
             for (int i = 0; i < CX; ++i) {
-                const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, H1p / KS, lane));
+                frag bf;
+                if constexpr (PF) bf = b4[kk][i];
+                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, NKH1, lane));
                 mma(acc[i], af, bf);
             }
         }
+        FNN_STAMP(9);
 #pragma unroll
         for (int i = 0; i < CX; ++i) {
             const int col = (wave * CX + i) * 16 + lr;
@@ -577,6 +685,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
         }
     }
+    FNN_STAMP(10);
 }
 
 template <typename T, int C1, int C2, int CX>
