@@ -60,6 +60,7 @@ struct fnn_handle {
     const int32_t* sorted_ids = nullptr; int sorted_B = 0;      // what slot[cur] holds (nullptr: nothing)
     const int32_t* next_ids = nullptr; int next_B = 0;          // pending fnn_prefetch_ids request
     bool key64 = false;
+    void* skeys = nullptr;              // phase-A output of the split sort
     double* cpow_dev = nullptr;
     std::vector<double> cpow_host; double cpow_c = -1.0; int cpow_n = 0;
     int* err_flag = nullptr;
@@ -183,21 +184,11 @@ template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes() {
     constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
     return (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
 }
-template <typename T, int C1, int C2, int CX, typename KT>
-void launch_step1_inst(hipStream_t s, const SortArgs& so, int nmlp, const MlpArgs<T>& a) {
-    size_t lds = mlp_lds_bytes<T, C1, C2, CX>();
-    if (so.nblk > 0 && sort_lds_bytes<KT>() > lds) lds = sort_lds_bytes<KT>();
-    hipLaunchKernelGGL((k_step1<T, C1, C2, CX, KT>), dim3(so.nblk + nmlp), dim3(256), lds, s, so, a);
-}
-template <typename T> void launch_step1(fnn_handle* h, const SortArgs& so, int nmlp, const MlpArgs<T>& a) {
-    const bool big = h->H1p / 64 == 5;
-    if (h->key64) {
-        if (big) launch_step1_inst<T, 5, 2, 4, unsigned long long>(h->st, so, nmlp, a);
-        else launch_step1_inst<T, 1, 1, 4, unsigned long long>(h->st, so, nmlp, a);
-    } else {
-        if (big) launch_step1_inst<T, 5, 2, 4, unsigned>(h->st, so, nmlp, a);
-        else launch_step1_inst<T, 1, 1, 4, unsigned>(h->st, so, nmlp, a);
-    }
+template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
+    if (h->H1p / 64 == 5)
+        hipLaunchKernelGGL((k_step1<T, 5, 2, 4>), dim3(nmlp), dim3(256), (mlp_lds_bytes<T, 5, 2, 4>()), h->st, a);
+    else
+        hipLaunchKernelGGL((k_step1<T, 1, 1, 4>), dim3(nmlp), dim3(256), (mlp_lds_bytes<T, 1, 1, 4>()), h->st, a);
 }
 void launch_sort16(fnn_handle* h, const SortArgs& so) {
     if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(so.nblk), dim3(256),
@@ -215,16 +206,14 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
     if (!(h->sorted_ids == ids && h->sorted_B == B)) {
         h->prefetch_misses++;
         ProfScope ps(h, "sort_now", h->st);
-        SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F};
+        SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F, h->skeys};
         launch_sort16(h, so);
     } else h->prefetch_hits++;
     const bool have_next = h->next_ids != nullptr && !(h->next_ids == ids && h->next_B == B);
     const int nxt = h->cur ^ 1;
     {
         ProfScope ps(h, "step1", h->st);
-        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? h->F : 0};
-        launch_step1<T>(h, so, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out));
+        launch_step1<T>(h, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out));
     }
     if (gx_out_dev) {
         const size_t n = (size_t)B * h->xdim;
@@ -236,7 +225,14 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
         ProfScope ps(h, "step2", h->st);
         const WgradArgs wa = make_wgrad_args<T>(h, Ba);
         const int nwx = wgrad_blocks(wa), nsc = h->F * SORT_N / 256;
-        hipLaunchKernelGGL((k_step2<T>), dim3(nwx * h->splitk + nsc), dim3(256), 0, h->st, wa, nwx, h->splitk, sa);
+        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                    have_next ? 4 * h->F : 0, h->skeys};
+        const dim3 grid(so.nblk + nwx * h->splitk + nsc);
+        if (h->key64)
+            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 1024 * 8, h->st, so, wa, nwx,
+                               h->splitk, sa);
+        else
+            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 1024 * 4, h->st, so, wa, nwx, h->splitk, sa);
     }
     {
         ProfScope ps(h, "step3", h->st);
@@ -244,8 +240,17 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
         TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
                     h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
                     h->w1, h->w1t, h->w2, h->w2t, nred};
-        if (update) hipLaunchKernelGGL((k_step3<T, true>), dim3(nred + 64), dim3(256), 0, h->st, ta, sa);
-        else hipLaunchKernelGGL((k_step3<T, false>), dim3(nred + 64), dim3(256), 0, h->st, ta, sa);
+        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                    have_next ? h->F : 0, h->skeys};
+        const dim3 grid(so.nblk + nred + 64);
+        const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
+        if (h->key64) {
+            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+            else hipLaunchKernelGGL((k_step3<T, false, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+        } else {
+            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+            else hipLaunchKernelGGL((k_step3<T, false, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+        }
     }
     if (have_next) { h->cur = nxt; h->sorted_ids = h->next_ids; h->sorted_B = h->next_B; }
     else { h->sorted_ids = nullptr; h->sorted_B = 0; }
@@ -281,8 +286,7 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     }
     if (h->fused && mlp_shape_ok(h)) {
         ProfScope ps(h, "mlp", h->st);
-        SortArgs none{nullptr, 0, F, h->n_rows, nullptr, nullptr, 0};
-        launch_step1<T>(h, none, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, train, p_out));
+        launch_step1<T>(h, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, train, p_out));
         if (!train) return FNN_OK;
     } else {
         {   // A3
@@ -424,7 +428,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
         CK(alloc_dev(h, &sl.owners, (size_t)h->F * (h->N2max / 16)));
         CK(alloc_dev(h, &sl.owner_cnt, (size_t)1));
     }
-    h->key64 = !((unsigned long long)h->cfg.max_batch <= 4096ull);   // refined when the table is set
+    h->key64 = true;                                                  // refined when the table is set
+    CK(alloc_dev(h, (char**)&h->skeys, (size_t)h->F * SORT_N * 8));
     CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
     CK(alloc_dev(h, &h->err_flag, (size_t)1));
     CK(alloc_dev(h, &h->ones_u8, (size_t)(h->H1p + h->H2p), false));
@@ -453,7 +458,7 @@ int fnn_destroy(fnn_handle* h)
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
-                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag, h->ones_u8,
+                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag, h->ones_u8, h->skeys,
                     h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : h->slot) {

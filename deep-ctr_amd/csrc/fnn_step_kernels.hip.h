@@ -3,9 +3,9 @@
 // One pass of the reference's hot loop body (python/FNN_wnzh.py:296-306) is three kernels on one
 // stream, each a union of two independent roles that run side by side on different workgroups:
 //
-//   k_step1 = { group the NEXT batch's (row, example) pairs by row }  U  { MLP strip kernel }
-//   k_step2 = { weight-gradient products, split-K }                    U  { sparse-row SGD, level 1 }
-//   k_step3 = { slab reduce + dense SGD + shadow refresh }             U  { sparse-row SGD, level 2 }
+//   k_step1 = { MLP strip kernel: gather, forward, loss, backward-data }
+//   k_step2 = { weight-gradient products } U { sparse-row SGD, level 1 } U { sort quarters of the NEXT batch's keys }
+//   k_step3 = { slab reduce + dense SGD + shadow refresh } U { sparse-row SGD, level 2 } U { merge the quarters }
 //
 // The step is a few microseconds of math, so its cost is launches and dependent memory round
 // trips; three fat launches and no cross-stream events are what that regime wants (measured:
@@ -25,7 +25,7 @@ template <typename KT> struct KeyTraits;
 template <> struct KeyTraits<unsigned> { static constexpr int SH = 12; };
 template <> struct KeyTraits<unsigned long long> { static constexpr int SH = 32; };
 
-struct SortArgs { const int32_t* ids; int B, F; int64_t n_rows; int4* rec; int* owner_cnt; int nblk; };
+struct SortArgs { const int32_t* ids; int B, F; int64_t n_rows; int4* rec; int* owner_cnt; int nblk; void* skeys; };
 
 constexpr int SORT_N = 4096;     // keys per field handled by the union-kernel path (B <= 4096)
 
@@ -33,7 +33,83 @@ template <typename KT> __host__ __device__ constexpr size_t sort_lds_bytes() {
     return (size_t)SORT_N * sizeof(KT) + 256 * sizeof(KT) + 2 * 256 * sizeof(int);
 }
 
+// Phase A of the split sort: one workgroup sorts a quarter (1024 keys, 256 threads x 4) of a
+// field's keys, ascending or descending as the full network would at k = 1024, and stores it.
 template <typename KT>
+__device__ __forceinline__ void sortA_body(const SortArgs& so, const int blk, unsigned char* smem)
+{
+    constexpr int SH = KeyTraits<KT>::SH;
+    const KT INV = ~(KT)0;
+    KT* s_key = reinterpret_cast<KT*>(smem);                 // [1024]
+    const int tid = threadIdx.x, F = so.F, B = so.B;
+    const int f = blk >> 2, base = (blk & 3) * 1024;
+    KT key[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                             // coalesced over tid; initial order is free
+        const int t = base + a * 256 + tid;
+        KT kk = INV;
+        if (t < B) {
+            const int64_t id = so.ids[(size_t)t * F + f];
+            if (id >= 0 && id < so.n_rows) kk = ((KT)id << SH) | (KT)t;
+        }
+        key[a] = kk;
+    }
+    const int i0 = base + tid * 4;                            // global position of key[0]
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < 4) {
+#pragma unroll
+                for (int jj = 2; jj > 0; jj >>= 1) {
+                    if (j == jj) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int b = a ^ jj;
+                            if (b > a) {
+                                const bool up = ((i0 + a) & k) == 0;
+                                const KT x = key[a], y = key[b];
+                                const KT mn = x < y ? x : y, mx = x < y ? y : x;
+                                key[a] = up ? mn : mx; key[b] = up ? mx : mn;
+                            }
+                        }
+                    }
+                }
+            } else {
+                const bool keepmin = ((i0 & j) == 0) == ((i0 & k) == 0);
+                if (j < 256) {
+                    const int d = j >> 2;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const KT other = __shfl_xor(key[a], d);
+                        const KT mine = key[a];
+                        const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                        key[a] = keepmin ? mn : mx;
+                    }
+                } else {
+                    __syncthreads();
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) s_key[tid * 4 + a] = key[a];
+                    __syncthreads();
+                    const int pt = (tid ^ (j >> 2)) * 4;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const KT other = s_key[pt + a];
+                        const KT mine = key[a];
+                        const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                        key[a] = keepmin ? mn : mx;
+                    }
+                }
+            }
+        }
+    }
+    KT* out = static_cast<KT*>(so.skeys) + (size_t)f * SORT_N + i0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) out[a] = key[a];
+}
+
+// The whole sort (MERGE = false) or phase B of the split sort (MERGE = true: the keys come from
+// phase A's four sorted quarters and only the merge levels k = 2048, 4096 remain), then the
+// segment bounds.
+template <typename KT, bool MERGE>
 __device__ __forceinline__ void sort16_body(const SortArgs& so, const int f, unsigned char* smem)
 {
     constexpr int SH = KeyTraits<KT>::SH;
@@ -45,17 +121,23 @@ __device__ __forceinline__ void sort16_body(const SortArgs& so, const int f, uns
     const int tid = threadIdx.x, F = so.F, B = so.B;
     if (f == 0 && tid == 0) *so.owner_cnt = 0;
     KT key[16];
+    if (MERGE) {
+        const KT* in = static_cast<const KT*>(so.skeys) + (size_t)f * SORT_N + tid * 16;
 #pragma unroll
-    for (int a = 0; a < 16; ++a) {                            // coalesced over tid; initial order is free
-        const int t = a * 256 + tid;
-        KT kk = INV;
-        if (t < B) {
-            const int64_t id = so.ids[(size_t)t * F + f];
-            if (id >= 0 && id < so.n_rows) kk = ((KT)id << SH) | (KT)t;
+        for (int a = 0; a < 16; ++a) key[a] = in[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {                        // coalesced over tid; initial order is free
+            const int t = a * 256 + tid;
+            KT kk = INV;
+            if (t < B) {
+                const int64_t id = so.ids[(size_t)t * F + f];
+                if (id >= 0 && id < so.n_rows) kk = ((KT)id << SH) | (KT)t;
+            }
+            key[a] = kk;
         }
-        key[a] = kk;
     }
-    for (int k = 2; k <= SORT_N; k <<= 1) {
+    for (int k = MERGE ? 2048 : 2; k <= SORT_N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j < 16) {
 #pragma unroll
@@ -143,30 +225,32 @@ template <typename KT>
 __global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    sort16_body<KT>(so, blockIdx.x, smem);
+    sort16_body<KT, false>(so, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
-// step 1: grouping of the next batch (first so.nblk workgroups)  U  MLP strips of this batch
+// step 1: MLP strips of this batch.  (At 256 VGPRs a strip workgroup fills its CU, so the sort
+// roles ride on steps 2 and 3, whose workgroups are small enough to share a CU.)
 // ------------------------------------------------------------------------------------------
-template <typename T, int C1, int C2, int CX, typename KT>
-__global__ __launch_bounds__(256) void k_step1(const SortArgs so, const MlpArgs<T> a)
+template <typename T, int C1, int C2, int CX>
+__global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    if ((int)blockIdx.x < so.nblk) sort16_body<KT>(so, blockIdx.x, smem);
-    else mlp_body<T, C1, C2, CX>(a, (int)blockIdx.x - so.nblk, smem);
+    mlp_body<T, C1, C2, CX>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
-// step 2: weight gradients (first nwx * splitk workgroups)  U  sparse-row SGD level 1
+// step 2: quarter-sorts of the NEXT batch's keys  U  weight gradients  U  sparse-row SGD level 1
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_step2(const WgradArgs wa, const int nwx, const int splitk,
-                                               const ScatArgs sa)
+template <typename T, typename KT>
+__global__ __launch_bounds__(256) void k_step2(const SortArgs so, const WgradArgs wa, const int nwx,
+                                               const int splitk, const ScatArgs sa)
 {
-    const int nw = nwx * splitk;
-    if ((int)blockIdx.x < nw) wgrad_body<T>(wa, (int)blockIdx.x % nwx, (int)blockIdx.x / nwx);
-    else scat1_body(sa, (int)blockIdx.x - nw);
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int b = blockIdx.x, nw = nwx * splitk;
+    if (b < so.nblk) sortA_body<KT>(so, b, smem);                              // so.nblk = 4 * F or 0
+    else if (b < so.nblk + nw) wgrad_body<T>(wa, (b - so.nblk) % nwx, (b - so.nblk) / nwx);
+    else scat1_body(sa, b - so.nblk - nw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,12 +264,14 @@ struct TailArgs {
     void *w1, *w1t, *w2, *w2t; int nblk_red;
 };
 
-template <typename T, bool UPDATE>
-__global__ __launch_bounds__(256) void k_step3(const TailArgs ta, const ScatArgs sa)
+template <typename T, bool UPDATE, typename KT>
+__global__ __launch_bounds__(256) void k_step3(const SortArgs so, const TailArgs ta, const ScatArgs sa)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_sum[16][16];
-    const int b = blockIdx.x;
-    if (b >= ta.nblk_red) { scat2_body(sa, b - ta.nblk_red, (int)gridDim.x - ta.nblk_red, s_sum); return; }
+    if ((int)blockIdx.x < so.nblk) { sort16_body<KT, true>(so, blockIdx.x, smem); return; }   // merge: F or 0 WGs
+    const int b = (int)blockIdx.x - so.nblk;
+    if (b >= ta.nblk_red) { scat2_body(sa, b - ta.nblk_red, (int)gridDim.x - so.nblk - ta.nblk_red, s_sum); return; }
     if (b == ta.nblk_red - 1) {                                // loss: fixed-shape tree
         float* s_l = reinterpret_cast<float*>(&s_sum[0][0]);
         float v = 0.f;
