@@ -71,9 +71,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    force_dp = bool(os.environ.get('FNN_BENCH_FORCE_DP'))      # exercise the DP code path with any world size
+    if world > 1 or force_dp:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     B = args.batch
@@ -114,7 +118,7 @@ def main():
         b = i % NB
         a = (h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, m1.data_ptr() + b * H1,
              m2.data_ptr() + b * H2, gB)
-        if world == 1:
+        if dist is None:
             rc = lib.fnn_train_step(*a, None, None, _capi.FNN_MEM_DEVICE, None)
         else:
             rc = lib.fnn_step_begin(*a, None, None, _capi.FNN_MEM_DEVICE)
@@ -175,7 +179,7 @@ def main():
             ach = per_ex * B / t_s / 1e12
             peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                    'frac': ach / peak, 'traffic': None, 'avg_launch_ms': cand[dom],
+                    'frac': ach / peak, 'traffic': pmc_traffic(dom), 'avg_launch_ms': cand[dom],
                     'algorithmic_per_example': per_ex,
                     'step': {'achieved': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9,
                              'frac': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -204,6 +208,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command; profiles/r01g_pmc_traffic.json, KB).
+    gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced
+    reads, so it is doubled (an upper bound for the mixed access widths of these kernels)."""
+    path = os.path.join(ROOT, 'profiles', 'r01g_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
+    for name, v in json.load(open(path)).items():
+        if tag and tag in name:
+            return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+    return None
 
 
 def cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, seconds):
