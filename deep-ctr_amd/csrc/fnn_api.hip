@@ -242,7 +242,7 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
                     h->w1, h->w1t, h->w2, h->w2t, nred};
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
                     have_next ? h->F : 0, h->skeys};
-        const dim3 grid(so.nblk + nred + 64);
+        const dim3 grid(so.nblk + nred + 256);       // 256 workgroups walk the multi-chunk segments
         const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
         if (h->key64) {
             if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
