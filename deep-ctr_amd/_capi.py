@@ -16,6 +16,7 @@ FNN_ERR_ARG, FNN_ERR_HIP, FNN_ERR_STATE, FNN_ERR_RANGE, FNN_ERR_NOMEM = -1, -2, 
 FNN_PREC_F32, FNN_PREC_BF16 = 0, 1
 FNN_ACT_TANH, FNN_ACT_SIGMOID, FNN_ACT_LINEAR = 0, 1, 2
 FNN_MEM_HOST, FNN_MEM_DEVICE = 0, 1
+FNN_MODE_FM, FNN_MODE_BAG = 0, 1
 
 
 class fnn_cfg(C.Structure):
@@ -23,7 +24,7 @@ class fnn_cfg(C.Structure):
                 ("hidden2", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32),
                 ("act", C.c_int32), ("reg_all", C.c_int32), ("lr", C.c_float),
                 ("lambda1", C.c_float), ("lambda_fm", C.c_float), ("device", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("mode", C.c_int32), ("h0", C.c_int32)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -42,6 +43,8 @@ SIGNATURES = {
     "fnn_get_rows": (_i, [_vp, _vp, _i64, _vp, _i]),
     "fnn_set_dense": (_i, [_vp, _i, _vp, _vp, _i]),
     "fnn_get_dense": (_i, [_vp, _i, _vp, _vp, _i]),
+    "fnn_set_bag_bias": (_i, [_vp, _vp, _i]),
+    "fnn_get_bag_bias": (_i, [_vp, _vp, _i]),
     "fnn_gather": (_i, [_vp, _vp, _i, _vp, _i]),
     "fnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.POINTER(_f)]),
     "fnn_prefetch_ids": (_i, [_vp, _vp, _i]),

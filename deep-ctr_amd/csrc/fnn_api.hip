@@ -39,6 +39,8 @@ struct fnn_handle {
     size_t n1 = 0, n2 = 0, nw12 = 0, nw = 0;
     int splitk = 8;
     bool bf16 = false;
+    bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
+    float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
     bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
     // FM table
     float* table16 = nullptr; int32_t* field_of_row = nullptr; int64_t n_rows = 0; float w0 = 0.f;
@@ -145,6 +147,9 @@ template <typename T> void launch_update(fnn_handle* h, const float* bucket, flo
     hipLaunchKernelGGL((k_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->master,
                        bucket, lr, h->cfg.lambda1, h->cfg.reg_all, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t,
                        (T*)h->w2, (T*)h->w2t);
+    if (h->bag && bucket)
+        hipLaunchKernelGGL(k_axpy, dim3((unsigned)((h->nbag + 255) / 256)), dim3(256), 0, h->st, h->bb0,
+                           bucket + h->nw, -lr, (int)h->nbag);
 }
 
 // the strip kernel is instantiated for the padded shapes in use; anything else takes the
@@ -160,15 +165,16 @@ template <typename T> WgradArgs make_wgrad_args(fnn_handle* h, int Ba) {
     wa.p[0] = WgradProb{h->xpT, h->dl1T, h->slab, h->K1p / 64, h->H1p / 64, h->H1p};
     wa.p[1] = WgradProb{h->d1T, h->dl2T, h->slab + h->n1, h->H1p / 64, h->H2p / 64, h->H2p};
     wa.p[2] = WgradProb{h->d2T, h->dl3T, h->slab + h->nw12, h->H2p / 64, 1, 64};     // gw3p = column 0
+    wa.p[3] = WgradProb{h->dlxT, h->onesT, h->slab + h->off_bag, h->bag ? h->K1p / 64 : 0, 1, 64};   // sum_t delta_t
     wa.ldT = h->ldT; wa.klen = Ba / h->splitk; wa.zstride = h->nslab;
     return wa;
 }
 int wgrad_blocks(const WgradArgs& wa) {
-    return wa.p[0].mt * wa.p[0].nt + wa.p[1].mt * wa.p[1].nt + wa.p[2].mt * wa.p[2].nt;
+    return wa.p[0].mt * wa.p[0].nt + wa.p[1].mt * wa.p[1].nt + wa.p[2].mt * wa.p[2].nt + wa.p[3].mt * wa.p[3].nt;
 }
 ScatArgs make_scat_args(fnn_handle* h, const fnn_handle::SortSlot& sl, int N2) {
     return ScatArgs{sl.rec, N2, h->F, h->K, h->gxp, h->K1p, h->cpow_dev, (double)h->cfg.lr, h->table16,
-                    sl.part, sl.owner_cnt, sl.owners};
+                    sl.part, sl.owner_cnt, sl.owners, h->rw};
 }
 template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids, const float* y, int B,
                                                 const uint8_t* m1, const uint8_t* m2, bool train, float* p_out) {
@@ -177,18 +183,26 @@ template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids
                       m1 ? m1 : h->ones_u8, m2 ? m2 : h->ones_u8, h->cfg.act, train ? ACT_TANH : h->cfg.act,
                       h->H1, h->H2, train ? 1 : 0,
                       (T*)h->xpT, (T*)h->d1T, (T*)h->d2T, (T*)h->dl1T, (T*)h->dl2T, (T*)h->dl3T, h->ldT,
-                      h->gxp, p_out, h->loss_t, h->err_flag};
+                      h->gxp, p_out, h->loss_t, h->err_flag, h->bb0, h->rw, (T*)h->dlxT, nullptr};
 }
-template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes() {
+template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int F) {
     constexpr int PAD = 16 / (int)sizeof(T);
     constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
-    return (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
+    size_t n = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
+    if (bag) n += (size_t)16 * 64 * CX * sizeof(float) + (size_t)16 * F * sizeof(int);
+    return n;
 }
 template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
-    if (h->H1p / 64 == 5)
-        hipLaunchKernelGGL((k_step1<T, 5, 2, 4>), dim3(nmlp), dim3(256), (mlp_lds_bytes<T, 5, 2, 4>()), h->st, a);
-    else
-        hipLaunchKernelGGL((k_step1<T, 1, 1, 4>), dim3(nmlp), dim3(256), (mlp_lds_bytes<T, 1, 1, 4>()), h->st, a);
+    const bool big = h->H1p / 64 == 5;
+    const size_t lds = big ? mlp_lds_bytes<T, 5, 2, 4>(h->bag, h->F) : mlp_lds_bytes<T, 1, 1, 4>(h->bag, h->F);
+    const dim3 g(nmlp), b(256);
+    if (h->bag) {
+        if (big) hipLaunchKernelGGL((k_step1<T, 5, 2, 4, true>), g, b, lds, h->st, a);
+        else hipLaunchKernelGGL((k_step1<T, 1, 1, 4, true>), g, b, lds, h->st, a);
+    } else {
+        if (big) hipLaunchKernelGGL((k_step1<T, 5, 2, 4, false>), g, b, lds, h->st, a);
+        else hipLaunchKernelGGL((k_step1<T, 1, 1, 4, false>), g, b, lds, h->st, a);
+    }
 }
 void launch_sort16(fnn_handle* h, const SortArgs& so) {
     if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(so.nblk), dim3(256),
@@ -213,18 +227,23 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
     const int nxt = h->cur ^ 1;
     {
         ProfScope ps(h, "step1", h->st);
-        launch_step1<T>(h, Ba / 16, make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out));
+        MlpArgs<T> ma = make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out);
+        if (h->bag && gx_out_dev) ma.gx_raw = h->gx_raw;
+        launch_step1<T>(h, Ba / 16, ma);
     }
     if (gx_out_dev) {
         const size_t n = (size_t)B * h->xdim;
-        hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, h->K1p,
-                           B, h->F, h->K, gx_out_dev);
+        if (h->bag) hipLaunchKernelGGL(k_copy_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gx_raw,
+                                       h->K1p, B, h->xdim, gx_out_dev);
+        else hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, h->K1p,
+                                B, h->F, h->K, gx_out_dev);
     }
     const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
     {
         ProfScope ps(h, "step2", h->st);
         const WgradArgs wa = make_wgrad_args<T>(h, Ba);
-        const int nwx = wgrad_blocks(wa), nsc = h->F * SORT_N / 256;
+        const int nwx = wgrad_blocks(wa);
+        const int nsc = h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256) : h->F * SORT_N / 256;
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
                     have_next ? 4 * h->F : 0, h->skeys};
         const dim3 grid(so.nblk + nwx * h->splitk + nsc);
@@ -236,10 +255,10 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
     }
     {
         ProfScope ps(h, "step3", h->st);
-        const int nred = (int)((h->nw + 255) / 256) + 1;
+        const int nred = (int)((h->nw + h->nbag + 255) / 256) + 1;
         TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
                     h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
-                    h->w1, h->w1t, h->w2, h->w2t, nred};
+                    h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
                     have_next ? h->F : 0, h->skeys};
         const dim3 grid(so.nblk + nred + 256);       // 256 workgroups walk the multi-chunk segments
@@ -272,6 +291,8 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     T *d2T = (T*)h->d2T, *dl3T = (T*)h->dl3T;
     fnn_handle::SortSlot& sl = h->slot[h->cur];
     h->sorted_ids = nullptr; h->next_ids = nullptr;            // this path keeps no grouping across steps
+    if (h->bag && !(h->fused && mlp_shape_ok(h))) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG needs the strip kernel (hidden sizes 300/100 or <=63/<=63)");
+    if (h->bag && train) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG trains through the three-launch path only (B <= 4096)");
 
     if (train) {   // A6 part 1: group the (row, t) pairs
         ProfScope ps(h, "sort", h->st);
@@ -375,7 +396,10 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     if (!cfg || !out) { g_create_err = "null argument"; return FNN_ERR_ARG; }
     *out = nullptr;
     if (cfg->n_fields < 2 || cfg->n_fields > 64) { g_create_err = "n_fields must be in [2, 64]"; return FNN_ERR_ARG; }
-    if (cfg->k < 1 || cfg->k > 15) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
+    if (cfg->mode != FNN_MODE_FM && cfg->mode != FNN_MODE_BAG) { g_create_err = "bad mode"; return FNN_ERR_ARG; }
+    if (cfg->mode == FNN_MODE_BAG && (cfg->h0 < 4 || cfg->h0 > 252 || cfg->h0 % 4 != 0 || cfg->max_batch > 4096)) {
+        g_create_err = "FNN_MODE_BAG: h0 must be a multiple of 4 in [4, 252] and max_batch <= 4096"; return FNN_ERR_ARG; }
+    if (cfg->mode == FNN_MODE_FM && (cfg->k < 1 || cfg->k > 15)) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
     if (cfg->hidden1 < 1 || cfg->hidden1 > 4095 || cfg->hidden2 < 1 || cfg->hidden2 > 255) { g_create_err = "hidden1 must be in [1, 4095], hidden2 in [1, 255]"; return FNN_ERR_ARG; }
     if (cfg->max_batch < 1 || cfg->max_batch > 16384) { g_create_err = "max_batch must be in [1, 16384] (per-field LDS sort)"; return FNN_ERR_ARG; }
     if (cfg->precision != FNN_PREC_F32 && cfg->precision != FNN_PREC_BF16) { g_create_err = "bad precision"; return FNN_ERR_ARG; }
@@ -398,6 +422,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->F = cfg->n_fields; h->K = cfg->k; h->H1 = cfg->hidden1; h->H2 = cfg->hidden2;
     h->xdim = 1 + h->F * h->K;
     h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
+    h->bag = cfg->mode == FNN_MODE_BAG;
+    if (h->bag) { h->rw = cfg->h0; h->K = cfg->h0; h->xdim = cfg->h0; h->K1p = rup(cfg->h0 + 1, 64); }
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     h->N2max = 256; while (h->N2max < h->Bmax) h->N2max <<= 1;
     h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
@@ -406,8 +432,10 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     if (const char* ev = getenv("FNN_NO_FUSE")) h->fused = !(ev[0] == '1');
     const size_t ts = tsize(h), Ba = h->ldT;
     CK(alloc_dev(h, &h->master, h->nw));
-    CK(alloc_dev(h, &h->bucket, h->nw));
-    h->nslab = h->nw12 + (size_t)h->H2p * 64;
+    h->off_bag = h->nw12 + (size_t)h->H2p * 64;
+    h->nbag = h->bag ? (size_t)h->K1p : 0;
+    CK(alloc_dev(h, &h->bucket, h->nw + h->nbag));
+    h->nslab = h->off_bag + h->nbag * 64;
     CK(alloc_dev(h, &h->slab, (size_t)h->splitk * h->nslab));
     CK(alloc_dev(h, (char**)&h->w1, h->n1 * ts));   CK(alloc_dev(h, (char**)&h->w1t, h->n1 * ts));
     CK(alloc_dev(h, (char**)&h->w2, h->n2 * ts));   CK(alloc_dev(h, (char**)&h->w2t, h->n2 * ts));
@@ -424,9 +452,24 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, &h->loss_dev, (size_t)1));
     for (auto& sl : h->slot) {
         CK(alloc_dev(h, &sl.rec, (size_t)h->F * h->N2max));
-        CK(alloc_dev(h, &sl.part, (size_t)h->F * (h->N2max / 16) * 2 * SLOT));
-        CK(alloc_dev(h, &sl.owners, (size_t)h->F * (h->N2max / 16)));
+        const size_t nchunk = h->bag ? (size_t)h->N2max / WCH : (size_t)h->N2max / 16;
+        CK(alloc_dev(h, &sl.part, (size_t)h->F * nchunk * 2 * h->rw));
+        CK(alloc_dev(h, &sl.owners, (size_t)h->F * nchunk));
         CK(alloc_dev(h, &sl.owner_cnt, (size_t)1));
+    }
+    if (h->bag) {
+        if (!mlp_shape_ok(h)) { h->err = "FNN_MODE_BAG needs hidden sizes the strip kernel is built for (300/100 or <=63/<=63)"; return fail(FNN_ERR_ARG); }
+        CK(alloc_dev(h, &h->bb0, (size_t)h->K1p));
+        CK(alloc_dev(h, (char**)&h->dlxT, Ba * h->K1p * ts));
+        CK(alloc_dev(h, (char**)&h->onesT, Ba * 64 * ts));
+        CK(alloc_dev(h, &h->gx_raw, Ba * h->K1p));
+        // onesT: fragment-tiled [64][ldT] matrix whose row 0 is all ones (column sums via MFMA)
+        std::vector<unsigned char> ones(Ba * 64 * ts, 0);
+        for (size_t t = 0; t < Ba; ++t) {
+            if (h->bf16) { const unsigned short one = 0x3F80; memcpy(&ones[ft_off<bf16_t>(0, (int)t, (int)Ba) * 2], &one, 2); }
+            else { const float one = 1.0f; memcpy(&ones[ft_off<float>(0, (int)t, (int)Ba) * 4], &one, 4); }
+        }
+        HK(hipMemcpy(h->onesT, ones.data(), ones.size(), hipMemcpyHostToDevice));
     }
     h->key64 = true;                                                  // refined when the table is set
     CK(alloc_dev(h, (char**)&h->skeys, (size_t)h->F * SORT_N * 8));
@@ -458,7 +501,7 @@ int fnn_destroy(fnn_handle* h)
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
-                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag, h->ones_u8, h->skeys,
+                    h->loss_t, h->d2T, h->dl3T, h->loss_dev, h->cpow_dev, h->err_flag, h->ones_u8, h->skeys, h->bb0, h->dlxT, h->onesT, h->gx_raw,
                     h->st_ids, h->st_y, h->st_m1, h->st_m2, h->st_p, h->st_x};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : h->slot) {
@@ -494,7 +537,7 @@ int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows, const int32_
     HIPCHK(h, hipStreamSynchronize(h->st));
     if (h->table16) { hipFree(h->table16); h->table16 = nullptr; }
     if (h->field_of_row) { hipFree(h->field_of_row); h->field_of_row = nullptr; }
-    HIPCHK(h, hipMalloc((void**)&h->table16, (size_t)n_rows * SLOT * sizeof(float)));
+    HIPCHK(h, hipMalloc((void**)&h->table16, (size_t)n_rows * h->rw * sizeof(float)));
     HIPCHK(h, hipMalloc((void**)&h->field_of_row, (size_t)n_rows * sizeof(int32_t)));
     const size_t nbytes = (size_t)n_rows * h->K * sizeof(float);
     const float* src = rows; float* tmp = nullptr;
@@ -503,8 +546,8 @@ int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows, const int32_
         HIPCHK(h, hipMemcpy(tmp, rows, nbytes, hipMemcpyHostToDevice));
         src = tmp;
     }
-    const size_t n = (size_t)n_rows * SLOT;
-    hipLaunchKernelGGL(k_pack_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, src, n_rows, h->K, h->table16);
+    const size_t n = (size_t)n_rows * h->rw;
+    hipLaunchKernelGGL(k_pack_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, src, n_rows, h->K, h->rw, h->table16);
     if (field_of_row)
         HIPCHK(h, hipMemcpyAsync(h->field_of_row, field_of_row, (size_t)n_rows * sizeof(int32_t),
                                  memkind == FNN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
@@ -536,7 +579,7 @@ static int get_rows_impl(fnn_handle* h, const int64_t* row_ids, int64_t n, float
         out_dev = tmp_out;
     }
     hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->st, h->table16,
-                       ids_dev, n, h->n_rows, h->K, out_dev, h->err_flag);
+                       ids_dev, n, h->n_rows, h->K, h->rw, out_dev, h->err_flag);
     int rc = FNN_OK;
     if (memkind == FNN_MEM_HOST) {
         HIPCHK(h, hipMemcpyAsync(out, tmp_out, cnt * sizeof(float), hipMemcpyDeviceToHost, h->st));
@@ -578,11 +621,16 @@ int fnn_set_dense(fnn_handle* h, int layer, const float* W, const float* b, int 
     HIPCHK(h, hipStreamSynchronize(h->st));
     if (layer == 1) {
         std::vector<float> p(h->n1, 0.f);
-        for (int f = 0; f < F; ++f)
-            for (int l = 0; l < K; ++l)
-                memcpy(&p[(size_t)(f * SLOT + l) * H1p], &hw[(size_t)(1 + f * K + l) * H1], H1 * 4);
-        memcpy(&p[(size_t)K * H1p], &hw[0], H1 * 4);                 // w1[0,:] rides on the w_0 slot
-        memcpy(&p[(size_t)(SLOT + K) * H1p], hb.data(), H1 * 4);     // b1 rides on the ones slot
+        if (h->bag) {                                                    // W [h0][H1]; b1 on the ones column h0
+            for (int i = 0; i < h->rw; ++i) memcpy(&p[(size_t)i * H1p], &hw[(size_t)i * H1], H1 * 4);
+            memcpy(&p[(size_t)h->rw * H1p], hb.data(), H1 * 4);
+        } else {
+            for (int f = 0; f < F; ++f)
+                for (int l = 0; l < K; ++l)
+                    memcpy(&p[(size_t)(f * SLOT + l) * H1p], &hw[(size_t)(1 + f * K + l) * H1], H1 * 4);
+            memcpy(&p[(size_t)K * H1p], &hw[0], H1 * 4);                 // w1[0,:] rides on the w_0 slot
+            memcpy(&p[(size_t)(SLOT + K) * H1p], hb.data(), H1 * 4);     // b1 rides on the ones slot
+        }
         HIPCHK(h, hipMemcpy(h->master, p.data(), h->n1 * 4, hipMemcpyHostToDevice));
     } else if (layer == 2) {
         std::vector<float> p(h->n2, 0.f);
@@ -613,11 +661,16 @@ int fnn_get_dense(fnn_handle* h, int layer, float* W, float* b, int memkind)
     const size_t nb = layer == 1 ? H1 : layer == 2 ? H2 : 1;
     std::vector<float> hw(nW), hb(nb);
     if (layer == 1) {
-        memcpy(&hw[0], &m[(size_t)K * H1p], H1 * 4);
-        for (int f = 0; f < F; ++f)
-            for (int l = 0; l < K; ++l)
-                memcpy(&hw[(size_t)(1 + f * K + l) * H1], &m[(size_t)(f * SLOT + l) * H1p], H1 * 4);
-        memcpy(hb.data(), &m[(size_t)(SLOT + K) * H1p], H1 * 4);
+        if (h->bag) {
+            for (int i = 0; i < h->rw; ++i) memcpy(&hw[(size_t)i * H1], &m[(size_t)i * H1p], H1 * 4);
+            memcpy(hb.data(), &m[(size_t)h->rw * H1p], H1 * 4);
+        } else {
+            memcpy(&hw[0], &m[(size_t)K * H1p], H1 * 4);
+            for (int f = 0; f < F; ++f)
+                for (int l = 0; l < K; ++l)
+                    memcpy(&hw[(size_t)(1 + f * K + l) * H1], &m[(size_t)(f * SLOT + l) * H1p], H1 * 4);
+            memcpy(hb.data(), &m[(size_t)(SLOT + K) * H1p], H1 * 4);
+        }
     } else if (layer == 2) {
         const float* p = &m[h->n1];
         for (int i = 0; i < H1; ++i) memcpy(&hw[(size_t)i * H2], &p[(size_t)i * H2p], H2 * 4);
@@ -630,6 +683,26 @@ int fnn_get_dense(fnn_handle* h, int layer, float* W, float* b, int memkind)
         HIPCHK(h, hipMemcpy(W, hw.data(), nW * 4, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(b, hb.data(), nb * 4, hipMemcpyHostToDevice));
     }
+    return FNN_OK;
+}
+
+int fnn_set_bag_bias(fnn_handle* h, const float* bb0, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!h->bag || !bb0) FAIL(h, FNN_ERR_ARG, "fnn_set_bag_bias: FNN_MODE_BAG handle and non-null pointer required");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    HIPCHK(h, hipMemcpy(h->bb0, bb0, (size_t)h->rw * 4, memkind == FNN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    return FNN_OK;
+}
+
+int fnn_get_bag_bias(fnn_handle* h, float* bb0_out, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!h->bag || !bb0_out) FAIL(h, FNN_ERR_ARG, "fnn_get_bag_bias: FNN_MODE_BAG handle and non-null pointer required");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    HIPCHK(h, hipMemcpy(bb0_out, h->bb0, (size_t)h->rw * 4, memkind == FNN_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
     return FNN_OK;
 }
 
@@ -648,8 +721,12 @@ int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memki
     const size_t n = (size_t)B * h->xdim;
     {
         ProfScope ps(h, "gather_ref", h->st);
-        hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
-                           h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
+        if (h->bag)
+            hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
+                               h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag);
+        else
+            hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
+                               h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
     }
     if (memkind == FNN_MEM_HOST) {
         HIPCHK(h, hipMemcpyAsync(x_out, x_dev, n * 4, hipMemcpyDeviceToHost, h->st));
@@ -718,7 +795,7 @@ int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B)
 int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats)
 {
     if (!h || !dev_ptr || !n_floats) return FNN_ERR_ARG;
-    *dev_ptr = h->bucket; *n_floats = (int64_t)h->nw;
+    *dev_ptr = h->bucket; *n_floats = (int64_t)(h->nw + h->nbag);
     return FNN_OK;
 }
 

@@ -297,27 +297,18 @@ __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
 // operands are fragment-tiled transposed activations.  A workgroup owns a 64 x 64 output block of
 // one product and one K slice (blockIdx.y); partial sums go to that slice's f32 slab.
 struct WgradProb { const void* A; const void* B; float* out; int mt, nt, ldo; };   // mt, nt: 64-blocks
-struct WgradArgs { WgradProb p[3]; int ldT, klen; size_t zstride; };
+struct WgradArgs { WgradProb p[4]; int ldT, klen; size_t zstride; };      // p[3]: bag-bias gradient (mt = 0 if unused)
 
 template <typename T>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by)
+__device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, const int by, const int ldT,
+                                           const int klen, const size_t zstride)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int KS = Traits<T>::KS;
-    // pick the product by scalar selects (a runtime index into the argument struct would spill it)
-    const int n0 = a.p[0].mt * a.p[0].nt, n1 = a.p[1].mt * a.p[1].nt;
-    const int pi = bx < n0 ? 0 : (bx < n0 + n1 ? 1 : 2);
-    const int b = bx - (pi == 0 ? 0 : (pi == 1 ? n0 : n0 + n1));
-    WgradProb pr;
-    pr.A = pi == 0 ? a.p[0].A : (pi == 1 ? a.p[1].A : a.p[2].A);
-    pr.B = pi == 0 ? a.p[0].B : (pi == 1 ? a.p[1].B : a.p[2].B);
-    pr.out = pi == 0 ? a.p[0].out : (pi == 1 ? a.p[1].out : a.p[2].out);
-    pr.nt = pi == 0 ? a.p[0].nt : (pi == 1 ? a.p[1].nt : a.p[2].nt);
-    pr.ldo = pi == 0 ? a.p[0].ldo : (pi == 1 ? a.p[1].ldo : a.p[2].ldo);
     const int bm = b / pr.nt, bn = b % pr.nt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rt = bm * 4 + wave, ct0 = bn * 4;
-    const int nkt_all = a.ldT / KS, kt0 = by * (a.klen / KS), nkt = a.klen / KS;
+    const int nkt_all = ldT / KS, kt0 = by * (klen / KS), nkt = klen / KS;
     const T* A = static_cast<const T*>(pr.A);
     const T* B = static_cast<const T*>(pr.B);
     f32x4 acc[4];
@@ -332,7 +323,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
             mma(acc[n], af, bf);
         }
     }
-    float* o = pr.out + (size_t)by * a.zstride;
+    float* o = pr.out + (size_t)by * zstride;
     const int r0 = rt * 16 + 4 * (lane >> 4);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -340,6 +331,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[(size_t)(r0 + r) * pr.ldo + col] = acc[n][r];
     }
+}
+
+// the product is picked with constant indices into the argument struct (a runtime index spills it)
+template <typename T>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by)
+{
+    const int n0 = a.p[0].mt * a.p[0].nt, n1 = a.p[1].mt * a.p[1].nt, n2 = a.p[2].mt * a.p[2].nt;
+    if (bx < n0) wgrad_tile<T>(a.p[0], bx, by, a.ldT, a.klen, a.zstride);
+    else if (bx < n0 + n1) wgrad_tile<T>(a.p[1], bx - n0, by, a.ldT, a.klen, a.zstride);
+    else if (bx < n0 + n1 + n2) wgrad_tile<T>(a.p[2], bx - n0 - n1, by, a.ldT, a.klen, a.zstride);
+    else wgrad_tile<T>(a.p[3], bx - n0 - n1 - n2, by, a.ldT, a.klen, a.zstride);
 }
 
 template <typename T>
@@ -362,6 +364,8 @@ template <typename T> struct MlpArgs {
     int act1, act2, H1, H2, train;
     T *xpT, *d1T, *d2T, *dl1T, *dl2T, *dl3T; int ldT;
     float *gxp, *p_out, *loss_t; int* err;
+    // embedding-bag input layer (SNN fine-tune, python/SNN_RBM.py:238-291); unused in FM mode
+    const float* bb0; int rw; T* dlxT; float* gx_raw;
 #ifdef FNN_STAMPS
     long long* dbg;                 // diagnostic build only: per-workgroup phase time stamps
 #endif
@@ -372,7 +376,11 @@ template <typename T> struct MlpArgs {
 #define FNN_STAMP(i) do { } while (0)
 #endif
 
-template <typename T, int C1, int C2, int CX>
+// BAG = false: layer one is the concatenation of the F gathered FM rows (FNN, :87-96).
+// BAG = true : layer one is x = sigmoid(sum of the F gathered rows of ww0 + bb0), rw floats wide
+//              (SNN, python/SNN_RBM.py:248-256), and the kernel returns
+//              delta = gx * x * (1 - x) (:288-290) instead of gx.
+template <typename T, int C1, int C2, int CX, bool BAG = false>
 __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, unsigned char* smem)
 {
     typedef typename Traits<T>::frag frag;
@@ -385,6 +393,8 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     T* sd1 = sx + 16 * LXM;                      // [16][L1]   d1
     T* sdl2 = sd1 + 16 * L1;                     // [16][L2]   delta2
     float* sz = reinterpret_cast<float*>(sdl2 + 16 * L2);   // [4][16]
+    float* sxf = sz + 64;                        // BAG: [16][K1p] f32 copy of x for delta
+    int* sids = reinterpret_cast<int*>(sxf + 16 * K1p);     // BAG: [16][F] ids of the strip
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int t0 = blk * 16;
@@ -428,6 +438,58 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
     }
 
+    if constexpr (BAG) {
+        // ---- P0 (bag): x = sigmoid(sum_f ww0[id_f] + bb0).  ids of the strip first (one per thread),
+        // then every thread sums the 16-byte quarter-columns it owns over the F rows: F independent
+        // loads in flight per item, rw/4 items per example.
+        const int rw = a.rw, nq = rw >> 2;
+        for (int e = tid; e < 16 * F; e += 256) {
+            const int t = t0 + e / F;
+            int id = -1;
+            if (t < B) {
+                id = a.ids[(size_t)t * F + e % F];
+                if (id < -1 || id >= a.n_rows) { atomicOr(a.err, 1); id = -1; }
+            }
+            sids[e] = id;
+        }
+        lds_barrier();
+        for (int e = tid; e < 16 * nq; e += 256) {
+            const int r = e / nq, c4 = e % nq;
+            float4 acc = *reinterpret_cast<const float4*>(a.bb0 + 4 * c4);
+            for (int f0 = 0; f0 < F; f0 += 8) {
+                float4 v[8]; float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = (f0 + u < F) ? sids[r * F + f0 + u] : -1;
+                    w[u] = id >= 0 ? 1.0f : 0.0f;
+                    v[u] = *reinterpret_cast<const float4*>(a.table16 + (size_t)(id < 0 ? 0 : id) * rw + 4 * c4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+                    acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+                }
+            }
+            const float live = (t0 + r < B) ? 1.0f : 0.0f;
+            const float x0 = sigmoid_fast(acc.x) * live, x1 = sigmoid_fast(acc.y) * live,
+                        x2 = sigmoid_fast(acc.z) * live, x3 = sigmoid_fast(acc.w) * live;
+            store4(sx + r * LX + 4 * c4, x0, x1, x2, x3);
+            *reinterpret_cast<float4*>(sxf + r * K1p + 4 * c4) = make_float4(x0, x1, x2, x3);
+        }
+        for (int e = tid; e < 16 * (K1p - rw); e += 256) {       // ones column (b1 row) + padding
+            const int r = e / (K1p - rw), c = rw + e % (K1p - rw);
+            const float v = (c == rw && t0 + r < B) ? 1.0f : 0.0f;
+            sx[r * LX + c] = (T)v; sxf[r * K1p + c] = 0.0f;
+        }
+        lds_barrier();
+        if (a.train) {
+            for (int e = tid; e < K1p * 4; e += 256) {
+                const int c = e >> 2, tq = e & 3;
+                store4(a.xpT + ft_off<T>(c, t0 + 4 * tq, ldT), (float)sx[(4 * tq) * LX + c], (float)sx[(4 * tq + 1) * LX + c],
+                       (float)sx[(4 * tq + 2) * LX + c], (float)sx[(4 * tq + 3) * LX + c]);
+            }
+        }
+    } else {
     // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96).
     // All ids first, then all rows: two dependent round trips for the whole strip.
     for (int e = tid; e < 16 * F; e += 256) {
@@ -472,6 +534,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     for (int e = tid; e < 16 * (K1p - F * SLOT); e += 256) {       // pad columns of the tile
         const int r = e / (K1p - F * SLOT), c = F * SLOT + e % (K1p - F * SLOT);
         sx[r * LX + c] = (T)0.f;
+    }
     }
     lds_barrier();
     FNN_STAMP(1);
@@ -681,8 +744,21 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < CX; ++i) {
             const int col = (wave * CX + i) * 16 + lr;
+            if constexpr (BAG) {       // delta = gx * x * (1 - x)  (python/SNN_RBM.py:288-290, lr applied later)
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * lq + r;
+                    const float xv = sxf[row * K1p + col];
+                    v[r] = acc[i][r] * xv * (1.0f - xv);          // sxf is 0 beyond column rw and row B
+                    a.gxp[(size_t)(t0 + row) * K1p + col] = v[r];
+                    if (a.gx_raw) a.gx_raw[(size_t)(t0 + row) * K1p + col] = acc[i][r];
+                }
+                store4(a.dlxT + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
+            }
         }
     }
     FNN_STAMP(10);
@@ -941,6 +1017,7 @@ __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, 
 struct ScatArgs {
     const int4* rec; int N2, F, K; const float* gxp; int K1p; const double* cpow; double lr;
     float* table16; double* part; int* owner_cnt; int4* owners;
+    int rw;          // 16: FM rows (decayed update); otherwise the bag-table row width (plain sum)
 };
 __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
 {
@@ -1023,17 +1100,124 @@ __global__ __launch_bounds__(256) void k_scat2(const ScatArgs sa)
     scat2_body(sa, blockIdx.x, gridDim.x, s_sum);
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse-row update of the bag table (python/SNN_RBM.py:285-291): ww0[f] -= lr * delta_t for
+// every example t that has feature f; no decay, so a row's result is row - lr * (sum of its
+// deltas) in example order.  Same sorted records as the FM path; rows are rw floats wide, so a
+// thread owns one 16-byte quarter-column of a chunk of 8 sorted entries.
+// ------------------------------------------------------------------------------------------
+constexpr int WCH = 8;           // sorted entries per chunk on the wide path
+
+__device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
+{
+    const int rw = sa.rw, nq = rw >> 2, N2 = sa.N2, NQ = N2 / WCH;
+    const long gid = (long)blk * 256 + threadIdx.x;
+    const int chunk = (int)(gid / nq), q = (int)(gid % nq);
+    if (chunk >= sa.F * NQ) return;
+    const int f = chunk / NQ, qc = chunk % NQ, base = qc * WCH;
+    int4 r[WCH];
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) r[j] = sa.rec[(size_t)f * N2 + base + j];
+    float4 g[WCH], wold[WCH];
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+        const bool live = r[j].x >= 0;
+        g[j] = *reinterpret_cast<const float4*>(sa.gxp + (size_t)(live ? r[j].y : 0) * sa.K1p + 4 * q);
+        wold[j] = *reinterpret_cast<const float4*>(sa.table16 + (size_t)(live ? r[j].x : 0) * rw + 4 * q);
+    }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+        if (r[j].x < 0) continue;
+        a0 += g[j].x; a1 += g[j].y; a2 += g[j].z; a3 += g[j].w;
+        const bool last = (j == WCH - 1) || (r[j + 1 < WCH ? j + 1 : WCH - 1].x != r[j].x);
+        if (!last) continue;
+        const int s = r[j].z, e = r[j].w;
+        if (s >= base && e <= base + WCH) {
+            *reinterpret_cast<float4*>(sa.table16 + (size_t)r[j].x * rw + 4 * q) =
+                make_float4((float)(wold[j].x - sa.lr * a0), (float)(wold[j].y - sa.lr * a1),
+                            (float)(wold[j].z - sa.lr * a2), (float)(wold[j].w - sa.lr * a3));
+        } else {
+            const int which = (s < base) ? 0 : 1;
+            double* pp = sa.part + (((size_t)f * NQ + qc) * 2 + which) * rw + 4 * q;
+            pp[0] = a0; pp[1] = a1; pp[2] = a2; pp[3] = a3;
+            if (which == 1 && q == 0) sa.owners[atomicAdd(sa.owner_cnt, 1)] = make_int4(f, s, e, r[j].x);
+        }
+        a0 = a1 = a2 = a3 = 0;
+    }
+}
+
+__device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, const int nblk, double* s_w /*[1024]*/)
+{
+    const int rw = sa.rw, nq = rw >> 2, NQ = sa.N2 / WCH, ngrp = 256 / nq;
+    const int grp = threadIdx.x / nq, q = threadIdx.x % nq;
+    const int n = *sa.owner_cnt;
+    for (int o = blk; o < n; o += nblk) {
+        const int4 ow = sa.owners[o];                      // {f, s, e, row}
+        const int q0 = ow.y / WCH, q1 = (ow.z - 1) / WCH;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (grp < ngrp) {
+            for (int qq = q0 + grp; qq <= q1; qq += ngrp) {
+                const double* pp = sa.part + (((size_t)ow.x * NQ + qq) * 2 + (qq == q0 ? 1 : 0)) * rw + 4 * q;
+                a0 += pp[0]; a1 += pp[1]; a2 += pp[2]; a3 += pp[3];
+            }
+            double* d = s_w + ((size_t)grp * nq + q) * 4;
+            d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            for (int gI = 0; gI < ngrp; ++gI) {
+                const double* d = s_w + ((size_t)gI * nq + q) * 4;
+                t0 += d[0]; t1 += d[1]; t2 += d[2]; t3 += d[3];
+            }
+            float4* p = reinterpret_cast<float4*>(sa.table16 + (size_t)ow.w * rw + 4 * q);
+            const float4 w = *p;
+            *p = make_float4((float)(w.x - sa.lr * t0), (float)(w.y - sa.lr * t1), (float)(w.z - sa.lr * t2),
+                             (float)(w.w - sa.lr * t3));
+        }
+        __syncthreads();
+    }
+}
+
+// reference-shaped outputs of the bag path: x [B][H0] = sigmoid(bag) and the raw gx [B][H0]
+__global__ void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw, const float* __restrict__ table,
+                          int64_t n_rows, const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)B * rw) return;
+    const int t = (int)(gid / rw), c = (int)(gid % rw);
+    float s = bb0[c];
+    for (int f = 0; f < F; ++f) {
+        int64_t id = ids[(size_t)t * F + f];
+        if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
+        if (id >= 0) s += table[(size_t)id * rw + c];
+    }
+    x[gid] = 1.0f / (1.0f + expf(-s));
+}
+__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+__global__ void k_copy_cols(const float* __restrict__ src, int ld, int B, int n, float* __restrict__ dst)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)B * n) return;
+    dst[gid] = src[(gid / n) * ld + gid % n];
+}
+
 // helpers for fnn_set_table / fnn_get_table / fnn_get_rows
-__global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int K,
+__global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int K, int stride,
                              float* __restrict__ table16)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)n_rows * SLOT) return;
-    const size_t r = gid / SLOT; const int l = (int)(gid % SLOT);
+    if (gid >= (size_t)n_rows * stride) return;
+    const size_t r = gid / stride; const int l = (int)(gid % stride);
     table16[gid] = (l < K) ? rows[r * K + l] : 0.f;
 }
 __global__ void k_unpack_rows(const float* __restrict__ table16, const int64_t* __restrict__ row_ids,
-                              int64_t n, int64_t n_rows, int K, float* __restrict__ out,
+                              int64_t n, int64_t n_rows, int K, int stride, float* __restrict__ out,
                               int* __restrict__ err)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1041,7 +1225,7 @@ __global__ void k_unpack_rows(const float* __restrict__ table16, const int64_t* 
     const size_t i = gid / K; const int l = (int)(gid % K);
     int64_t r = row_ids ? row_ids[i] : (int64_t)i;
     if (r < 0 || r >= n_rows) { atomicOr(err, 1); out[gid] = 0.f; return; }
-    out[gid] = table16[(size_t)r * SLOT + l];
+    out[gid] = table16[(size_t)r * stride + l];
 }
 
 }  // namespace fnn

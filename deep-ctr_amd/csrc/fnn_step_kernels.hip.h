@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
 // step 1: MLP strips of this batch.  (At 256 VGPRs a strip workgroup fills its CU, so the sort
 // roles ride on steps 2 and 3, whose workgroups are small enough to share a CU.)
 // ------------------------------------------------------------------------------------------
-template <typename T, int C1, int C2, int CX>
+template <typename T, int C1, int C2, int CX, bool BAG>
 __global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    mlp_body<T, C1, C2, CX>(a, blockIdx.x, smem);
+    mlp_body<T, C1, C2, CX, BAG>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_step2(const SortArgs so, const WgradArg
     const int b = blockIdx.x, nw = nwx * splitk;
     if (b < so.nblk) sortA_body<KT>(so, b, smem);                              // so.nblk = 4 * F or 0
     else if (b < so.nblk + nw) wgrad_body<T>(wa, (b - so.nblk) % nwx, (b - so.nblk) / nwx);
-    else scat1_body(sa, b - so.nblk - nw);
+    else if (sa.rw == SLOT) scat1_body(sa, b - so.nblk - nw);
+    else scatw1_body(sa, b - so.nblk - nw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -262,6 +263,7 @@ struct TailArgs {
     const float* slab; int splitk; size_t nw_all, nw12, nslab; float* master; float lambda1; int reg_all;
     const float* loss_t; int Ba; float* bucket; float* loss_sum; float lr; int K1p, H1p, H2p;
     void *w1, *w1t, *w2, *w2t; int nblk_red;
+    float* bb0; size_t nbag, off_bag;      // bag mode: bias vector, its length (K1p) and slab offset
 };
 
 template <typename T, bool UPDATE, typename KT>
@@ -271,7 +273,12 @@ __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const TailArgs
     __shared__ double s_sum[16][16];
     if ((int)blockIdx.x < so.nblk) { sort16_body<KT, true>(so, blockIdx.x, smem); return; }   // merge: F or 0 WGs
     const int b = (int)blockIdx.x - so.nblk;
-    if (b >= ta.nblk_red) { scat2_body(sa, b - ta.nblk_red, (int)gridDim.x - so.nblk - ta.nblk_red, s_sum); return; }
+    if (b >= ta.nblk_red) {
+        const int nb = (int)gridDim.x - so.nblk - ta.nblk_red;
+        if (sa.rw == SLOT) scat2_body(sa, b - ta.nblk_red, nb, s_sum);
+        else scatw2_body(sa, b - ta.nblk_red, nb, reinterpret_cast<double*>(smem));
+        return;
+    }
     if (b == ta.nblk_red - 1) {                                // loss: fixed-shape tree
         float* s_l = reinterpret_cast<float*>(&s_sum[0][0]);
         float v = 0.f;
@@ -286,7 +293,16 @@ __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const TailArgs
         return;
     }
     const size_t i = (size_t)b * 256 + threadIdx.x;
-    if (i >= ta.nw_all) return;
+    if (i >= ta.nw_all + ta.nbag) return;
+    if (i >= ta.nw_all) {               // bag bias: bb0 -= lr * sum_t delta_t  (python/SNN_RBM.py:289)
+        const size_t c = i - ta.nw_all;
+        float g = 0.f;
+#pragma unroll 8
+        for (int z = 0; z < ta.splitk; ++z) g += ta.slab[(size_t)z * ta.nslab + ta.off_bag + c * 64];
+        ta.bucket[i] = g;
+        if (UPDATE) ta.bb0[c] -= ta.lr * g;
+        return;
+    }
     const size_t src = (i < ta.nw12) ? i : ta.nw12 + (i - ta.nw12) * 64;
     float g = 0.f;
 #pragma unroll 8

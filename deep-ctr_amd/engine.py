@@ -28,7 +28,8 @@ class FNNEngine(object):
     """
 
     def __init__(self, n_fields=16, k=11, hidden1=300, hidden2=100, max_batch=4096, precision='bf16',
-                 acti_type='tanh', lr=0.001, lambda1=0.0, lambda_fm=0.1, reg_all=False, device=0):
+                 acti_type='tanh', lr=0.001, lambda1=0.0, lambda_fm=0.1, reg_all=False, device=0,
+                 mode='fm', hidden0=0):
         import torch
         if not torch.cuda.is_available():
             raise FNNError(_capi.FNN_ERR_HIP, "no HIP device visible to PyTorch-ROCm; the FNN hot path has "
@@ -39,12 +40,16 @@ class FNNEngine(object):
         self.stream = torch.cuda.Stream(device=self.device)
         self.F, self.K, self.H1, self.H2 = n_fields, k, hidden1, hidden2
         self.xdim = 1 + n_fields * k
+        self.bag = mode == 'bag'               # SNN fine-tune input layer (python/SNN_RBM.py:238-291)
+        if self.bag:
+            self.K = self.xdim = hidden0
         self.max_batch = max_batch
         self.precision = precision
         cfg = _capi.fnn_cfg(n_fields, k, hidden1, hidden2, max_batch,
                             _capi.FNN_PREC_BF16 if precision == 'bf16' else _capi.FNN_PREC_F32,
                             _ACTS[acti_type], 1 if reg_all else 0, lr, lambda1, lambda_fm, device,
-                            C.c_void_p(self.stream.cuda_stream))
+                            C.c_void_p(self.stream.cuda_stream),
+                            _capi.FNN_MODE_BAG if self.bag else _capi.FNN_MODE_FM, hidden0)
         h = C.c_void_p()
         rc = self.lib.fnn_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -112,6 +117,16 @@ class FNNEngine(object):
         self._ck(self.lib.fnn_get_rows(self.h, ids.ctypes.data, ids.shape[0], out.ctypes.data,
                                        _capi.FNN_MEM_HOST))
         return out
+
+    def set_bag_bias(self, bb0):
+        b = np.ascontiguousarray(bb0, dtype=np.float32)
+        assert b.shape == (self.K,)
+        self._ck(self.lib.fnn_set_bag_bias(self.h, b.ctypes.data, _capi.FNN_MEM_HOST))
+
+    def get_bag_bias(self):
+        b = np.empty(self.K, dtype=np.float32)
+        self._ck(self.lib.fnn_get_bag_bias(self.h, b.ctypes.data, _capi.FNN_MEM_HOST))
+        return b
 
     def set_dense(self, p):
         """p: dict w1 [xdim,H1], b1 [H1], w2 [H1,H2], b2 [H2], w3 [H2], b3 scalar."""

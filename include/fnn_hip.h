@@ -53,6 +53,15 @@ extern "C" {
 #define FNN_MEM_HOST    0
 #define FNN_MEM_DEVICE  1
 
+/* Input layer.  FM: x = [w_0 | rows of the F active features]  (python/FNN_wnzh.py:87-96).
+ * BAG: x = sigmoid(sum of the rows of ww0 of the active features + bb0), the SNN fine-tune of
+ * python/SNN_RBM.py:238-291; then the table is ww0 [n_rows, h0], layer 1 is W [h0, H1],
+ * fnn_gather returns x [B, h0], gx_out is [B, h0], `k` is ignored, lambda1 usually comes with
+ * reg_all = 1 (:141-143), and the sparse update is ww0[f] -= lr*gx*x*(1-x) (no decay) with
+ * bb0 -= lr * sum_t gx*x*(1-x). */
+#define FNN_MODE_FM     0
+#define FNN_MODE_BAG    1
+
 typedef struct fnn_cfg {
     int32_t n_fields;     /* F: 16 for iPinYou (python/FNN_wnzh.py:51-53)     */
     int32_t k;            /* K = rank + 1: row = [w, v_1..v_rank]  (:76)      */
@@ -69,6 +78,9 @@ typedef struct fnn_cfg {
     float   lambda_fm;    /* :49                                              */
     int32_t device;       /* HIP device ordinal                               */
     void*   stream;       /* hipStream_t to run on, or NULL = create one      */
+    int32_t mode;         /* FNN_MODE_FM (FNN) or FNN_MODE_BAG (SNN fine-tune) */
+    int32_t h0;           /* FNN_MODE_BAG: width of the bag rows / of x
+                             (hidden0, python/SNN_RBM.py:25,53); multiple of 4 */
 } fnn_cfg;
 
 typedef struct fnn_handle fnn_handle;
@@ -97,6 +109,10 @@ int fnn_get_rows(fnn_handle* h, const int64_t* row_ids, int64_t n, float* out, i
  * layer 3: W [H2], b [1]. */
 int fnn_set_dense(fnn_handle* h, int layer, const float* W, const float* b, int memkind);
 int fnn_get_dense(fnn_handle* h, int layer, float* W, float* b, int memkind);
+
+/* FNN_MODE_BAG only: the bias bb0 [h0] of the bag layer (python/SNN_RBM.py:78,255,289). */
+int fnn_set_bag_bias(fnn_handle* h, const float* bb0, int memkind);
+int fnn_get_bag_bias(fnn_handle* h, float* bb0_out, int memkind);
 
 /* A3: x_out [B, 1+F*K] = layer-one array of every example. */
 int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memkind);

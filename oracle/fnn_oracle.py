@@ -341,3 +341,38 @@ def run_epochs(p, rows, w_0, train_ids, train_y, test_ids, test_y, batch_size, l
         if times_reduce < 0:
             break
     return hist
+
+
+# --------------------------------------------------------------------------- A8 (SNN fine-tune)
+def snn_bag(ww0, bb0, ids):
+    """python/SNN_RBM.py:238-262 get_fi_h1_y: x = sigmoid(sum_{f active} ww0[f] + bb0);
+    ids [B,F] int, -1 = no feature (a feature whose value is not 1 does not count, :251)."""
+    B, F = ids.shape
+    s = np.tile(np.asarray(bb0, dtype=np.float64), (B, 1))
+    for f in range(F):
+        m = ids[:, f] >= 0
+        s[m] += ww0[ids[m, f]]
+    return 1.0 / (1.0 + np.exp(-s))
+
+
+def snn_train_step(p, ww0, bb0, ids, y, r1, r2, lr, lambda1, acti_type='tanh'):
+    """One pass of python/SNN_RBM.py:281-291: x from the bag (pre-update ww0/bb0), train(x, y)
+    with lambda1 on all six dense tensors (:141-143), then per example, in order,
+    delta = lr*gx[t]*x[t]*(1-x[t]); bb0 -= delta; ww0[f] -= delta for each active f.
+    Mutates p, ww0, bb0 (bb0 must be an ndarray)."""
+    x = snn_bag(ww0, bb0, ids)
+    gx, pre, loss, p_drop, g = train_call(p, x, y, r1, r2, lr, lambda1, acti_type, reg_all=True)
+    B, F = ids.shape
+    for t in range(B):
+        d = lr * gx[t] * x[t] * (1 - x[t])
+        bb0 -= d
+        for f in range(F):
+            r = ids[t, f]
+            if r >= 0:
+                ww0[r] = ww0[r] - d
+    return {'x': x, 'gx': gx, 'loss': loss, 'p_drop': p_drop, 'grads': g, 'pre': pre}
+
+
+def snn_predict(p, ww0, bb0, ids, acti_type='tanh'):
+    """python/SNN_RBM.py:162-198 auc_rmse's forward: bag -> predict."""
+    return predict(p, snn_bag(ww0, bb0, ids), acti_type)

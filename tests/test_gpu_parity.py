@@ -477,3 +477,102 @@ def test_full_shape_properties(built, full_problem, prec):
     assert np.array_equal(tab_all[mask], rows[mask])
     g_again, tab_again = run(slice(0, B))
     assert np.array_equal(g_all, g_again) and np.array_equal(tab_all, tab_again)
+
+
+# ----------------------------------------------------------------- SNN fine-tune path (A8)
+def make_snn_problem(B, n_rows=600, h0=200, seed=0, dup_col=None, empty=()):
+    sizes = synth.field_sizes_tiny(n_rows)
+    rng = np.random.RandomState(seed)
+    ww0 = (rng.standard_normal((sum(sizes), h0)) * 0.1).astype(np.float32)
+    bb0 = (rng.standard_normal(h0) * 0.1).astype(np.float32)
+    ids = synth.zipf_ids(B, sizes, 1.1, seed + 1)
+    if dup_col is not None:
+        ids[:, dup_col] = ids[0, dup_col]
+    for (t, f) in empty:
+        ids[t, f] = -1
+    y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    dl = __import__('deep_ctr_amd').dl_utils
+    p = {'w1': f32r(rng.uniform(-0.3, 0.3, (h0, H1))), 'b1': f32r(rng.uniform(-0.1, 0.1, H1)),
+         'w2': f32r(rng.uniform(-0.3, 0.3, (H1, H2))), 'b2': f32r(rng.uniform(-0.1, 0.1, H2)),
+         'w3': f32r(rng.uniform(-0.2, 0.2, H2)), 'b3': 0.05}
+    r1 = (rng.uniform(size=H1) < 0.9).astype(np.uint8)
+    r2 = (rng.uniform(size=H2) < 0.9).astype(np.uint8)
+    return ww0, bb0, ids, y, p, r1, r2
+
+
+def make_snn_engine(ww0, bb0, p, prec='f32', lr=0.01, lam1=0.001, h0=200):
+    eng = FNNEngine(F, 0, H1, H2, max_batch=4096, precision=prec, lr=lr, lambda1=lam1, lambda_fm=0.0,
+                    reg_all=True, mode='bag', hidden0=h0)
+    eng.set_table(ww0, np.zeros(ww0.shape[0], np.int32), 0.0)
+    eng.set_bag_bias(bb0)
+    eng.set_dense(p)
+    return eng
+
+
+@pytest.mark.parametrize("B,kw", [(1, {}), (37, {"empty": [(3, 2)]}), (300, {"dup_col": 6}), (1000, {})])
+def test_snn_step_f32_vs_oracle(built, B, kw):
+    """A8: bag + sigmoid gather, MLP with L2 on all six tensors, per-example row updates without
+    decay (python/SNN_RBM.py:238-291) against the float64 oracle."""
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(B, seed=B, **kw)
+    eng = make_snn_engine(ww0, bb0, p)
+    x = eng.gather(ids).cpu().numpy()
+    ww64, bb64 = ww0.astype(np.float64), bb0.astype(np.float64)
+    np.testing.assert_allclose(x, orc.snn_bag(ww64, bb64, ids), rtol=2e-6, atol=1e-7)
+    out = eng.train_step(ids, y, r1, r2, want_p=True, want_gx=True)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ref = orc.snn_train_step(p64, ww64, bb64, ids, y.astype(np.float64), r1.astype(float), r2.astype(float),
+                             0.01, 0.001)
+    np.testing.assert_allclose(out['p'].cpu().numpy(), ref['p_drop'], rtol=2e-4, atol=1e-6)
+    gs = np.abs(ref['gx']).max()
+    np.testing.assert_allclose(out['gx'].cpu().numpy(), ref['gx'], rtol=2e-3, atol=2e-5 * gs + 1e-9)
+    assert abs(out['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    upd = np.abs(ww64 - ww0).max() + 1e-12
+    assert np.abs(eng.get_table() - ww64).max() <= 1e-3 * upd + 2e-7
+    bupd = np.abs(bb64 - bb0).max() + 1e-12
+    assert np.abs(eng.get_bag_bias() - bb64).max() <= 1e-3 * bupd + 2e-7
+    d = eng.get_dense()
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+        scale = np.abs(p64[k] - p[k]).max() + 1e-12
+        assert np.abs(d[k] - p64[k]).max() <= 1e-3 * scale + 1e-7, k
+    pr = eng.predict(ids).cpu().numpy()
+    np.testing.assert_allclose(pr, orc.snn_predict(p64, ww64, bb64, ids), rtol=3e-4, atol=1e-6)
+    eng.close()
+
+
+def test_snn_step_bf16_tracks_oracle(built):
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(512, seed=5, dup_col=3)
+    eng = make_snn_engine(ww0, bb0, p, prec='bf16')
+    out = eng.train_step(ids, y, r1, r2, want_p=True)
+    ww64, bb64 = ww0.astype(np.float64), bb0.astype(np.float64)
+    ref = orc.snn_train_step(p, ww64, bb64, ids, y.astype(np.float64), r1.astype(float), r2.astype(float), 0.01, 0.001)
+    assert np.abs(out['p'].cpu().numpy() - ref['p_drop']).max() < 3e-2
+    assert abs(out['loss'] - ref['loss']) < 3e-2 * ref['loss']
+    upd = np.abs(ww64 - ww0).max()
+    assert np.abs(eng.get_table() - ww64).max() < 8e-2 * upd + 1e-6
+    eng.close()
+
+
+def test_snn_full_shape_reproducible(built):
+    """BASELINE config 5 shape for the fine-tune step: 937,670 x 200 table (750 MB), batch 4096;
+    two runs are bitwise identical and untouched rows keep their bits."""
+    h0, B = 200, 4096
+    sizes = synth.field_sizes_ipinyou()
+    rng = np.random.RandomState(0)
+    ww0 = np.random.default_rng(0).standard_normal((sum(sizes), h0), dtype=np.float32) * np.float32(0.05)
+    bb0 = np.zeros(h0, np.float32)
+    ids = synth.zipf_ids(B, sizes, 1.1, 1)
+    y = (rng.uniform(size=B) < 0.02).astype(np.float32)
+    _, _, _, _, p, r1, r2 = make_snn_problem(4, seed=1)
+    res = []
+    for _ in range(2):
+        eng = make_snn_engine(ww0, bb0, p, prec='bf16', lr=0.001, lam1=0.0)
+        eng.train_step(ids, y, r1, r2)
+        touched = np.unique(ids)
+        res.append((eng.get_rows(touched), eng.get_bag_bias(), eng.get_rows(np.array([5, 77777, 500000]))))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    untouched = np.setdiff1d(np.array([5, 77777, 500000]), np.unique(ids))
+    for i, r in enumerate([5, 77777, 500000]):
+        if r in untouched:
+            assert np.array_equal(res[0][2][i], ww0[r])
+    assert not np.array_equal(res[0][0], ww0[np.unique(ids)])
