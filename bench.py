@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn'],
+                    help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -98,10 +100,23 @@ def main():
     m1_np = o1.draw().astype(np.uint8)
     m2_np = o2.draw().astype(np.uint8)
 
-    eng = FNNEngine(F, K, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
-                    lambda_fm=0.1, device=local_rank)
-    eng.set_table(rows, fo, -3.0)
-    eng.set_dense(p0)
+    snn = args.workload == 'snn'
+    H0 = 200
+    if snn:       # python/SNN_RBM.py:52-58: H0=200, H1=300, H2=100, lr=.001, dropout=.98, lambda1=0
+        eng = FNNEngine(F, 0, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
+                        lambda_fm=0.0, reg_all=True, device=local_rank, mode='bag', hidden0=H0)
+        ww0 = np.random.default_rng(1234).standard_normal((sum(sizes), H0), dtype=np.float32) * np.float32(0.05)
+        eng.set_table(ww0, fo, 0.0)
+        eng.set_bag_bias(np.zeros(H0, np.float32))
+        ut.seed_global(1234)
+        w1s, _ = ut.init_weight(H0, H1, 'sigmoid'); w2s, _ = ut.init_weight(H1, H2, 'sigmoid')
+        eng.set_dense({'w1': w1s, 'b1': np.zeros(H1), 'w2': w2s, 'b2': np.zeros(H2), 'w3': np.zeros(H2), 'b3': 0.0})
+        del ww0
+    else:
+        eng = FNNEngine(F, K, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
+                        lambda_fm=0.1, device=local_rank)
+        eng.set_table(rows, fo, -3.0)
+        eng.set_dense(p0)
     ids = torch.as_tensor(ids_np).to(dev).contiguous()
     y = torch.as_tensor(y_np).to(dev).contiguous()
     m1 = torch.as_tensor(m1_np).to(dev).contiguous()
@@ -171,6 +186,8 @@ def main():
         cand = {k: v for k, v in merged.items() if k in ALGO and ALGO[k][1] > 0}
         dom = max(cand, key=cand.get)
         bound, per_ex = ALGO[dom]
+        if snn:       # bag forward 64 + 16*800 B; update 2*12,800 + 800 B per example
+            bound, per_ex = {'step1': ('hbm', 64 + 16 * 800), 'step2': ('hbm', 2 * 16 * 800 + 800)}.get(dom, (bound, per_ex))
         t_s = cand[dom] * 1e-3
         if bound == 'hbm':
             ach = per_ex * B / t_s / 1e9
@@ -179,15 +196,15 @@ def main():
             ach = per_ex * B / t_s / 1e12
             peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                    'frac': ach / peak, 'traffic': pmc_traffic(dom), 'avg_launch_ms': cand[dom],
+                    'frac': ach / peak, 'traffic': None if snn else pmc_traffic(dom), 'avg_launch_ms': cand[dom],
                     'algorithmic_per_example': per_ex,
-                    'step': {'achieved': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9,
-                             'frac': STEP_MIN_BYTES * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'step': {'achieved': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9,
+                             'frac': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'unit': 'GB/s'}}
 
     # ---- CPU baseline: the C port of the oracle on this host, 1 core, bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not snn:
         cpu = cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
 
     if rank == 0:
@@ -196,8 +213,10 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': 'FNN L3 train step: 16 fields, 937670 one-hot dims, k=10, hidden 300/100 '
-                                   'tanh, batch 4096 per GPU, Zipf(1.1) ids',
+            'config': {'workload': ('SNN fine-tune step: 16 fields, 937670 x 200 bag table, hidden 300/100 tanh, batch '
+                                    '4096 per GPU, Zipf(1.1) ids' if snn else
+                                    'FNN L3 train step: 16 fields, 937670 one-hot dims, k=10, hidden 300/100 '
+                                    'tanh, batch 4096 per GPU, Zipf(1.1) ids'),
                        'per_gpu_batch': B, 'global_batch': gB,
                        'parallelism': 'dp%d' % world if world > 1 else 'single'},
             'train_logloss_last_step': last_loss,

@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_scat2(const ScatArgs sa)
 // deltas) in example order.  Same sorted records as the FM path; rows are rw floats wide, so a
 // thread owns one 16-byte quarter-column of a chunk of 8 sorted entries.
 // ------------------------------------------------------------------------------------------
-constexpr int WCH = 8;           // sorted entries per chunk on the wide path
+constexpr int WCH = 32;          // sorted entries per chunk on the wide path (4 sub-batches of 8 loads)
 
 __device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
 {
@@ -1115,35 +1115,37 @@ __device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
     const int chunk = (int)(gid / nq), q = (int)(gid % nq);
     if (chunk >= sa.F * NQ) return;
     const int f = chunk / NQ, qc = chunk % NQ, base = qc * WCH;
-    int4 r[WCH];
-#pragma unroll
-    for (int j = 0; j < WCH; ++j) r[j] = sa.rec[(size_t)f * N2 + base + j];
-    float4 g[WCH], wold[WCH];
-#pragma unroll
-    for (int j = 0; j < WCH; ++j) {
-        const bool live = r[j].x >= 0;
-        g[j] = *reinterpret_cast<const float4*>(sa.gxp + (size_t)(live ? r[j].y : 0) * sa.K1p + 4 * q);
-        wold[j] = *reinterpret_cast<const float4*>(sa.table16 + (size_t)(live ? r[j].x : 0) * rw + 4 * q);
-    }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int sb = 0; sb < WCH; sb += 8) {
+        int4 r[8];
 #pragma unroll
-    for (int j = 0; j < WCH; ++j) {
-        if (r[j].x < 0) continue;
-        a0 += g[j].x; a1 += g[j].y; a2 += g[j].z; a3 += g[j].w;
-        const bool last = (j == WCH - 1) || (r[j + 1 < WCH ? j + 1 : WCH - 1].x != r[j].x);
-        if (!last) continue;
-        const int s = r[j].z, e = r[j].w;
-        if (s >= base && e <= base + WCH) {
-            *reinterpret_cast<float4*>(sa.table16 + (size_t)r[j].x * rw + 4 * q) =
-                make_float4((float)(wold[j].x - sa.lr * a0), (float)(wold[j].y - sa.lr * a1),
-                            (float)(wold[j].z - sa.lr * a2), (float)(wold[j].w - sa.lr * a3));
-        } else {
-            const int which = (s < base) ? 0 : 1;
-            double* pp = sa.part + (((size_t)f * NQ + qc) * 2 + which) * rw + 4 * q;
-            pp[0] = a0; pp[1] = a1; pp[2] = a2; pp[3] = a3;
-            if (which == 1 && q == 0) sa.owners[atomicAdd(sa.owner_cnt, 1)] = make_int4(f, s, e, r[j].x);
+        for (int j = 0; j < 8; ++j) r[j] = sa.rec[(size_t)f * N2 + base + sb + j];
+        if (r[0].x < 0) break;                               // invalid keys sort to the end
+        float4 g[8], wold[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = r[j].x >= 0;
+            g[j] = *reinterpret_cast<const float4*>(sa.gxp + (size_t)(live ? r[j].y : 0) * sa.K1p + 4 * q);
+            wold[j] = *reinterpret_cast<const float4*>(sa.table16 + (size_t)(live ? r[j].x : 0) * rw + 4 * q);
         }
-        a0 = a1 = a2 = a3 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (r[j].x < 0) continue;
+            a0 += g[j].x; a1 += g[j].y; a2 += g[j].z; a3 += g[j].w;
+            const int pos = base + sb + j, s = r[j].z, e = r[j].w;
+            if (pos + 1 != e && pos + 1 != base + WCH) continue;       // the run goes on inside this chunk
+            if (s >= base && e <= base + WCH) {                      // the whole segment lies in this chunk
+                *reinterpret_cast<float4*>(sa.table16 + (size_t)r[j].x * rw + 4 * q) =
+                    make_float4((float)(wold[j].x - sa.lr * a0), (float)(wold[j].y - sa.lr * a1),
+                                (float)(wold[j].z - sa.lr * a2), (float)(wold[j].w - sa.lr * a3));
+            } else {
+                const int which = (s < base) ? 0 : 1;
+                double* pp = sa.part + (((size_t)f * NQ + qc) * 2 + which) * rw + 4 * q;
+                pp[0] = a0; pp[1] = a1; pp[2] = a2; pp[3] = a3;
+                if (which == 1 && q == 0) sa.owners[atomicAdd(sa.owner_cnt, 1)] = make_int4(f, s, e, r[j].x);
+            }
+            a0 = a1 = a2 = a3 = 0;
+        }
     }
 }
 
