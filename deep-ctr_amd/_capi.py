@@ -58,6 +58,21 @@ SIGNATURES = {
     "fnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 
+_d = C.c_double
+# every symbol include/rbm_hip.h declares
+RBM_SIGNATURES = {
+    "rbm_last_error": (C.c_char_p, []),
+    "rbm_sparse_epoch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _f, _f, _f, _f, C.POINTER(_d), _vp]),
+    "rbm_dense_create": (_i, [_i, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "rbm_dense_destroy": (_i, [_vp]),
+    "rbm_dense_set": (_i, [_vp, _vp, _vp, _vp]),
+    "rbm_dense_get": (_i, [_vp, _vp, _vp, _vp]),
+    "rbm_dense_cd1": (_i, [_vp, _vp, _i, _vp, _f, _f, _f, _f, _f, C.POINTER(_d)]),
+    "rbm_bag_sum": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
+    "rbm_affine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rbm_sigmoid": (_i, [_vp, _i64, _vp]),
+}
+
 _lib = None
 
 
@@ -77,7 +92,7 @@ def load():
             "libfnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

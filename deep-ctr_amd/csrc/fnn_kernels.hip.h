@@ -148,7 +148,7 @@ __device__ inline float dact_fn(float d, int act) {
 // four lanes of a row read one aligned 64-B piece and both output layouts get 4-element stores.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ ids, int B, int Ba, int F,
+static __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ ids, int B, int Ba, int F,
                                                 int K, const float* __restrict__ table16,
                                                 int64_t n_rows, float w0, T* __restrict__ xp, int K1p,
                                                 T* __restrict__ xpT, int ldT, int* __restrict__ err)
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ ids,
 }
 
 // Reference-layout gather for fnn_gather(): x [B][1+F*K] float (python/FNN_wnzh.py:91-96).
-__global__ void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
+static __global__ void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
                              const float* __restrict__ table16, int64_t n_rows, float w0,
                              float* __restrict__ x, int* __restrict__ err)
 {
@@ -205,7 +205,7 @@ __global__ void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int 
 }
 
 // gx' [B][K1p] (slot layout) -> gx [B][1+F*K] (what `train` returns, python/FNN_wnzh.py:179).
-__global__ void k_gx_ref(const float* __restrict__ gxp, int K1p, int B, int F, int K,
+static __global__ void k_gx_ref(const float* __restrict__ gxp, int K1p, int B, int F, int K,
                          float* __restrict__ gx)
 {
     const int xdim = 1 + F * K;
@@ -264,7 +264,7 @@ struct EpiF32 {                               // plain float output (gx', split-
 };
 
 template <typename T, int NT, typename Epi>
-__global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
+static __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
                                               const T* __restrict__ Bft, int klen, Epi epi)
 {
     typedef typename Traits<T>::frag frag;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) { wgrad_body<T>(a, blockIdx.x, blockIdx.y); }
+static __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) { wgrad_body<T>(a, blockIdx.x, blockIdx.y); }
 
 // ------------------------------------------------------------------------------------------
 // Fused MLP strip kernel: A3 gather -> A4 forward -> loss -> A5 backward-data for 16 examples per
@@ -765,7 +765,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 }
 
 template <typename T, int C1, int C2, int CX>
-__global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
+static __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     mlp_body<T, C1, C2, CX>(a, blockIdx.x, smem);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void k_mlp(const MlpArgs<T> a)
 // columns of every 64-column chunk.  block = 256 threads = 64 rows.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p, int H2,
+static __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p, int H2,
                                               const float* __restrict__ w3p,
                                               const uint8_t* __restrict__ mask2,
                                               const float* __restrict__ y, int B, int train,
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void k_head(const T* __restrict__ d2, int H2p,
 // gradient, which is what data parallelism all-reduces); the last block sums the per-example losses.
 // Slab z = [W1p grads n1 | W2p grads n2 | gw3p as column 0 of an [H2p][64] tile].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, int splitk,
+static __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, int splitk,
                                                 size_t nw_all, size_t nw12, size_t nslab,
                                                 const float* __restrict__ master, float lambda1,
                                                 int reg_all, const float* __restrict__ loss_t, int Ba,
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slab, 
 // theta <- theta - lr * (g + L2 term)  (python/FNN_wnzh.py:173,179-182) on the f32 masters, then refresh the
 // compute-precision shadows in both orientations, fragment-tiled (ft_off).
 template <typename T>
-__global__ void k_update(float* __restrict__ master, const float* __restrict__ bucket, float lr,
+static __global__ void k_update(float* __restrict__ master, const float* __restrict__ bucket, float lr,
                          float lambda1, int reg_all, int K1p, int H1p, int H2p, T* __restrict__ w1,
                          T* __restrict__ w1t, T* __restrict__ w2, T* __restrict__ w2t)
 {
@@ -930,7 +930,7 @@ __global__ void k_update(float* __restrict__ master, const float* __restrict__ b
 //             reproducible.
 // ------------------------------------------------------------------------------------------
 template <int KPT>
-__global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, int B, int F,
+static __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, int B, int F,
                                                int64_t n_rows, int N2, int4* __restrict__ rec,
                                                int* __restrict__ owner_cnt)
 {
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
     }
 }
 
-__global__ __launch_bounds__(256) void k_scat1(const ScatArgs sa) { scat1_body(sa, blockIdx.x); }
+static __global__ __launch_bounds__(256) void k_scat1(const ScatArgs sa) { scat1_body(sa, blockIdx.x); }
 
 __device__ __forceinline__ void scat2_body(const ScatArgs& sa, const int blk, const int nblk, double (*s_sum)[16])
 {
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void scat2_body(const ScatArgs& sa, const int blk, co
     }
 }
 
-__global__ __launch_bounds__(256) void k_scat2(const ScatArgs sa)
+static __global__ __launch_bounds__(256) void k_scat2(const ScatArgs sa)
 {
     __shared__ double s_sum[16][16];
     scat2_body(sa, blockIdx.x, gridDim.x, s_sum);
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
 }
 
 // reference-shaped outputs of the bag path: x [B][H0] = sigmoid(bag) and the raw gx [B][H0]
-__global__ void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw, const float* __restrict__ table,
+static __global__ void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw, const float* __restrict__ table,
                           int64_t n_rows, const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1197,12 +1197,12 @@ __global__ void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw,
     }
     x[gid] = 1.0f / (1.0f + expf(-s));
 }
-__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, int n)
+static __global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += a * x[i];
 }
-__global__ void k_copy_cols(const float* __restrict__ src, int ld, int B, int n, float* __restrict__ dst)
+static __global__ void k_copy_cols(const float* __restrict__ src, int ld, int B, int n, float* __restrict__ dst)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)B * n) return;
@@ -1210,7 +1210,7 @@ __global__ void k_copy_cols(const float* __restrict__ src, int ld, int B, int n,
 }
 
 // helpers for fnn_set_table / fnn_get_table / fnn_get_rows
-__global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int K, int stride,
+static __global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int K, int stride,
                              float* __restrict__ table16)
 {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1218,7 +1218,7 @@ __global__ void k_pack_table(const float* __restrict__ rows, int64_t n_rows, int
     const size_t r = gid / stride; const int l = (int)(gid % stride);
     table16[gid] = (l < K) ? rows[r * K + l] : 0.f;
 }
-__global__ void k_unpack_rows(const float* __restrict__ table16, const int64_t* __restrict__ row_ids,
+static __global__ void k_unpack_rows(const float* __restrict__ table16, const int64_t* __restrict__ row_ids,
                               int64_t n, int64_t n_rows, int K, int stride, float* __restrict__ out,
                               int* __restrict__ err)
 {

@@ -222,7 +222,7 @@ __device__ __forceinline__ void sort16_body(const SortArgs& so, const int f, uns
 }
 
 template <typename KT>
-__global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
+static __global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     sort16_body<KT, false>(so, blockIdx.x, smem);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
 // roles ride on steps 2 and 3, whose workgroups are small enough to share a CU.)
 // ------------------------------------------------------------------------------------------
 template <typename T, int C1, int C2, int CX, bool BAG>
-__global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
+static __global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     mlp_body<T, C1, C2, CX, BAG>(a, blockIdx.x, smem);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
 // step 2: quarter-sorts of the NEXT batch's keys  U  weight gradients  U  sparse-row SGD level 1
 // ------------------------------------------------------------------------------------------
 template <typename T, typename KT>
-__global__ __launch_bounds__(256) void k_step2(const SortArgs so, const WgradArgs wa, const int nwx,
+static __global__ __launch_bounds__(256) void k_step2(const SortArgs so, const WgradArgs wa, const int nwx,
                                                const int splitk, const ScatArgs sa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -267,7 +267,7 @@ struct TailArgs {
 };
 
 template <typename T, bool UPDATE, typename KT>
-__global__ __launch_bounds__(256) void k_step3(const SortArgs so, const TailArgs ta, const ScatArgs sa)
+static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const TailArgs ta, const ScatArgs sa)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_sum[16][16];

@@ -1,0 +1,440 @@
+// rbm_api.hip -- SNN pre-training kernels and their C ABI (include/rbm_hip.h), gfx950 only.
+// Replaces the NumPy CD-1 trainers of python/sampling_based_gaussian_binary_rbm_sparse.py
+// (Atomu2014/deep-ctr): sparse online CD-1 (:294-508) and dense mini-batch CD-1 (:10-291).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fnn_hip.h"
+#include "../../include/rbm_hip.h"
+#include "fnn_kernels.hip.h"
+
+using namespace fnn;
+
+namespace {
+
+thread_local std::string g_err;
+#define RCK(expr)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e_); return FNN_ERR_HIP; } \
+    } while (0)
+#define RFAIL(code, msg) do { g_err = (msg); return (code); } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+__device__ inline float sigm(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// ------------------------------------------------------------------------------------------
+// A7  sparse online CD-1 (python :423-505).  The trainer is sequential by definition (every
+// example reads the rows the previous one wrote), so ONE workgroup walks the examples; thread i
+// owns hidden unit i: column i of the S gathered rows (registers), of the positional momentum
+// buffer (registers) and hidbias[i].  The visible reconstruction is the only cross-thread step:
+// 8 lanes per visible unit reduce hs . W[f,:] through LDS.
+// ------------------------------------------------------------------------------------------
+struct SparseArgs {
+    float *W, *visbias, *hidbias, *wstep; const int32_t* vid; const uint8_t* vval; const float* unif;
+    int64_t N; int H, S; float wcost, r_vis, r_hid, r_w, mom; double* sq_err;
+};
+
+__global__ __launch_bounds__(256) void k_rbm_sparse(const SparseArgs a)
+{
+    __shared__ float s_w[32][257];
+    __shared__ float s_hs[256], s_vis[32], s_v[32], s_e[32];
+    __shared__ int s_id[32];
+    const int tid = threadIdx.x, H = a.H, S = a.S;
+    const bool act = tid < H;
+    float ws[32], hb = act ? a.hidbias[tid] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ws[j] = (act && j < S) ? a.wstep[(size_t)j * H + tid] : 0.f;
+    double err = 0.0;
+    for (int64_t n = 0; n < a.N; ++n) {
+        if (tid < 32) {
+            s_id[tid] = tid < S ? a.vid[n * S + tid] : 0;
+            s_v[tid] = tid < S ? (float)a.vval[n * S + tid] : 0.f;
+        }
+        __syncthreads();
+        float wc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wc[j] = (act && j < S) ? a.W[(size_t)s_id[j] * H + tid] : 0.f;
+        float z = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z = fmaf(s_v[j], wc[j], z);
+        const float hid = sigm(z);                                         // hid_activate(mf=True)
+        const float u = act ? a.unif[n * H + tid] : 2.f;
+        s_hs[tid] = act ? ((u < hid) ? 1.0f : floorf(hid)) : 0.f;          // sample_hid (:371-375)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_w[j][tid] = wc[j];
+        __syncthreads();
+        {   // vis_j = sigmoid(hs . W[f_j,:] + visbias[f_j])  (mean field, :356-366)
+            const int j = tid >> 3, seg = tid & 7;
+            float acc = 0.f;
+            for (int i = seg; i < H; i += 8) acc = fmaf(s_hs[i], s_w[j][i], acc);
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            if (seg == 0) {
+                const float vj = j < S ? sigm(acc + a.visbias[s_id[j]]) : 0.f;
+                s_vis[j] = vj;
+                const float d = vj - s_v[j];
+                s_e[j] = j < S ? d * d : 0.f;
+                if (j < S) a.visbias[s_id[j]] += (s_v[j] - vj) * a.r_vis;   // :472-484
+            }
+        }
+        __syncthreads();
+        float z2 = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z2 = fmaf(s_vis[j], wc[j], z2);
+        const float hid2 = sigm(z2);                                        // mean-field hiddens
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float step = ((s_v[j] * hid - s_vis[j] * hid2) - a.wcost * wc[j]) * a.r_w;   // :447-453
+            ws[j] = ws[j] * a.mom + step;                                   // :454-455
+            if (act && j < S) a.W[(size_t)s_id[j] * H + tid] = wc[j] + 2.0f * ws[j];    // applied twice (:461-462)
+        }
+        hb += (hid - hid2) * a.r_hid;                                       // :492-495
+        if (tid == 0) { float e = 0.f; for (int j = 0; j < 32; ++j) e += s_e[j]; err += (double)e; }
+        __syncthreads();          // W / visbias stores are drained (vmcnt 0) before the next example reads
+    }
+    if (act) a.hidbias[tid] = hb;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) if (act && j < S) a.wstep[(size_t)j * H + tid] = ws[j];
+    if (tid == 0 && a.sq_err) *a.sq_err = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// A7'  dense CD-1 (python :219-281) on the MFMA kernels of the FNN path.  Parameters live in
+// one padded matrix Wp [Kp][Hp]: Wp[r][c] = W, row nvis = hidbias, column nhid = visbias, so
+// hid = sigmoid(X' Wp) and vis = sigmoid(hs' Wp^T) pick their biases up from a ones column, and
+// the two correlation products X'^T hid' - vis'^T hid2' also deliver both bias steps
+// (row nvis = posact - sum hid2, column nhid = batchsum - sum vis).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_rbm_prep(const float* __restrict__ X, int n, int nvis, int Na, int Kp, int ldT,
+                           T* __restrict__ Xr, T* __restrict__ XT)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // (t quad, column)
+    if (gid >= (size_t)(Na / 4) * Kp) return;
+    const int c = (int)(gid % Kp), t0 = (int)(gid / Kp) * 4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + i;
+        v[i] = (t < n) ? (c < nvis ? X[(size_t)t * nvis + c] : (c == nvis ? 1.0f : 0.0f)) : 0.0f;
+        Xr[(size_t)t * Kp + c] = (T)v[i];
+    }
+    store4(XT + ft_off<T>(c, t0, ldT), v[0], v[1], v[2], v[3]);
+}
+
+template <typename T>
+__global__ void k_rbm_binarise(const T* __restrict__ hid, const float* __restrict__ unif, int n, int nhid,
+                               int Na, int Hp, T* __restrict__ hs)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)Na * Hp) return;
+    const int t = (int)(gid / Hp), c = (int)(gid % Hp);
+    float v = 0.f;
+    if (t < n) {
+        if (c < nhid) { const float p = (float)hid[gid]; v = (unif[(size_t)t * nhid + c] < p) ? 1.0f : floorf(p); }
+        else if (c == nhid) v = 1.0f;
+    }
+    hs[gid] = (T)v;
+}
+
+template <typename T>
+__global__ void k_rbm_sqerr(const T* __restrict__ vis, const float* __restrict__ X, int n, int nvis, int Kp,
+                            double* __restrict__ part)
+{
+    __shared__ double s[256];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n * nvis; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i / nvis), c = (int)(i % nvis);
+        const double d = (double)(float)vis[(size_t)t * Kp + c] - (double)X[i];
+        acc += d * d;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+template <typename T>
+__global__ void k_rbm_update(const float* __restrict__ slab, int splitk, size_t nslab, size_t off_neg,
+                             float* __restrict__ Wp, float* __restrict__ wsp, int nvis, int nhid, int Kp, int Hp,
+                             float inv_n, float wcost, float r_vis, float r_hid, float r_w, float mom, int apply,
+                             T* __restrict__ wf, T* __restrict__ wtf)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Kp * Hp) return;
+    const int r = (int)(i / Hp), c = (int)(i % Hp);
+    float w = Wp[i];
+    if (apply) {
+        float corr = 0.f;
+#pragma unroll 8
+        for (int z = 0; z < splitk; ++z) corr += slab[(size_t)z * nslab + i] - slab[(size_t)z * nslab + off_neg + i];
+        if (r < nvis && c < nhid) {                                   // :240-249
+            const float step = (corr * inv_n - wcost * w) * r_w;
+            const float m = wsp[i] * mom + step;
+            wsp[i] = m; w += m;
+        } else if (r == nvis && c < nhid) w += corr * (r_hid * inv_n);   // hidbias  (:268-273)
+        else if (c == nhid && r < nvis) w += corr * (r_vis * inv_n);     // visbias  (:262-266)
+        Wp[i] = w;
+    }
+    wf[ft_off<T>(c, r, Kp)] = (T)w;        // forward:  output column c (hidden), contraction over r
+    wtf[ft_off<T>(r, c, Hp)] = (T)w;       // backward: output column r (visible), contraction over c
+}
+
+__global__ void k_bag_sum(const float* __restrict__ W0, const float* __restrict__ b0, int H, int64_t n_rows,
+                          const int32_t* __restrict__ ids, int n, int F, float* __restrict__ out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * H) return;
+    const int t = (int)(gid / H), c = (int)(gid % H);
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const int64_t id = ids[(size_t)t * F + f];
+        if (id >= 0 && id < n_rows) s += W0[(size_t)id * H + c];
+    }
+    out[gid] = s + b0[c];
+}
+__global__ void k_affine(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                         int n, int a, int b, float* __restrict__ out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * b) return;
+    const int t = (int)(gid / b), c = (int)(gid % b);
+    float s = 0.f;
+    for (int k = 0; k < a; ++k) s = fmaf(in[(size_t)t * a + k], W[(size_t)k * b + c], s);
+    out[gid] = s + bias[c];
+}
+__global__ void k_sigmoid(float* __restrict__ x, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) x[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
+}  // namespace
+
+struct rbm_handle {
+    int nvis = 0, nhid = 0, Kp = 0, Hp = 0, max_n = 0, Na_max = 0, dev = 0, splitk = 8;
+    bool bf16 = false;
+    hipStream_t st = nullptr; bool own_stream = false;
+    float *Wp = nullptr, *wsp = nullptr, *slab = nullptr;
+    void *wf = nullptr, *wtf = nullptr;                                   // tiled shadows (T)
+    void *Xr = nullptr, *XT = nullptr, *hid = nullptr, *hidT = nullptr, *hs = nullptr, *vis = nullptr, *visT = nullptr,
+         *hid2 = nullptr, *hid2T = nullptr;
+    uint8_t* ones = nullptr; double* errpart = nullptr;
+    size_t nW = 0;
+};
+
+namespace {
+
+template <typename T> void rbm_refresh(rbm_handle* h, int apply, float inv_n, float wcost, float rv, float rh, float rw, float mom) {
+    const size_t n = h->nW;
+    hipLaunchKernelGGL((k_rbm_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->slab, h->splitk,
+                       2 * h->nW, h->nW, h->Wp, h->wsp, h->nvis, h->nhid, h->Kp, h->Hp, inv_n, wcost, rv, rh, rw, mom,
+                       apply, (T*)h->wf, (T*)h->wtf);
+}
+
+template <typename T>
+int rbm_step(rbm_handle* h, const float* X, int n, const float* unif, float wcost, float rv, float rh, float rw,
+             float mom, double* sq_err_out)
+{
+    const int Na = rup(n, 256), Kp = h->Kp, Hp = h->Hp, ldT = h->Na_max;
+    T *Xr = (T*)h->Xr, *XT = (T*)h->XT, *hid = (T*)h->hid, *hidT = (T*)h->hidT, *hs = (T*)h->hs, *vis = (T*)h->vis,
+      *visT = (T*)h->visT, *hid2 = (T*)h->hid2, *hid2T = (T*)h->hid2T;
+    {
+        const size_t nt = (size_t)(Na / 4) * Kp;
+        hipLaunchKernelGGL((k_rbm_prep<T>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, X, n, h->nvis, Na, Kp,
+                           ldT, Xr, XT);
+    }
+    {   // hid = sigmoid(X' Wp)   (hid_activate, mean field)
+        EpiFwd<T> e{hid, Hp, hidT, ldT, h->ones, ACT_SIGMOID, h->nhid, n};
+        hipLaunchKernelGGL((k_gemm<T, 4, EpiFwd<T>>), dim3(Na / 64, Hp / 64, 1), dim3(256), 0, h->st, Xr, Kp,
+                           (const T*)h->wf, Kp, e);
+    }
+    {
+        const size_t nt = (size_t)Na * Hp;
+        hipLaunchKernelGGL((k_rbm_binarise<T>), dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, hid, unif, n,
+                           h->nhid, Na, Hp, hs);
+    }
+    {   // vis = sigmoid(hs' Wp^T)   (mean-field visibles)
+        EpiFwd<T> e{vis, Kp, visT, ldT, h->ones, ACT_SIGMOID, h->nvis, n};
+        hipLaunchKernelGGL((k_gemm<T, 4, EpiFwd<T>>), dim3(Na / 64, Kp / 64, 1), dim3(256), 0, h->st, hs, Hp,
+                           (const T*)h->wtf, Hp, e);
+    }
+    {   // hid2 = sigmoid(vis' Wp)   (mean-field hiddens)
+        EpiFwd<T> e{hid2, Hp, hid2T, ldT, h->ones, ACT_SIGMOID, h->nhid, n};
+        hipLaunchKernelGGL((k_gemm<T, 4, EpiFwd<T>>), dim3(Na / 64, Hp / 64, 1), dim3(256), 0, h->st, vis, Kp,
+                           (const T*)h->wf, Kp, e);
+    }
+    {   // poscorr = X'^T hid',  negcorr = vis'^T hid2'   (contraction over the examples)
+        WgradArgs wa;
+        wa.p[0] = WgradProb{XT, hidT, h->slab, Kp / 64, Hp / 64, Hp};
+        wa.p[1] = WgradProb{visT, hid2T, h->slab + h->nW, Kp / 64, Hp / 64, Hp};
+        wa.p[2] = WgradProb{nullptr, nullptr, nullptr, 0, 1, 64};
+        wa.p[3] = WgradProb{nullptr, nullptr, nullptr, 0, 1, 64};
+        wa.ldT = ldT; wa.klen = Na / h->splitk; wa.zstride = 2 * h->nW;
+        const int nb = 2 * (Kp / 64) * (Hp / 64);
+        hipLaunchKernelGGL((k_wgrad<T>), dim3(nb, h->splitk), dim3(256), 0, h->st, wa);
+    }
+    if (sq_err_out)
+        hipLaunchKernelGGL((k_rbm_sqerr<T>), dim3(256), dim3(256), 0, h->st, vis, X, n, h->nvis, Kp, h->errpart);
+    rbm_refresh<T>(h, 1, 1.0f / (float)n, wcost, rv, rh, rw, mom);
+    RCK(hipGetLastError());
+    if (sq_err_out) {
+        std::vector<double> part(256);
+        RCK(hipMemcpyAsync(part.data(), h->errpart, 256 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+        RCK(hipStreamSynchronize(h->st));
+        double s = 0; for (double v : part) s += v;
+        *sq_err_out = s;
+    }
+    return FNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rbm_last_error(void) { return g_err.c_str(); }
+
+int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep, const int32_t* vid,
+                     const uint8_t* vval, const float* unif, int64_t N, int H, int S, float weightcost,
+                     float rate_vis, float rate_hid, float rate_w, float momentum, double* sq_err_out, void* stream)
+{
+    if (!W || !visbias || !hidbias || !wstep || !vid || !vval || !unif) RFAIL(FNN_ERR_ARG, "null pointer");
+    if (H < 1 || H > 256 || S < 1 || S > 32 || N < 1) RFAIL(FNN_ERR_ARG, "need 1 <= H <= 256, 1 <= S <= 32, N >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
+    hipStream_t st = (hipStream_t)stream;
+    double* d_err = nullptr;
+    RCK(hipMalloc((void**)&d_err, sizeof(double)));
+    SparseArgs a{W, visbias, hidbias, wstep, vid, vval, unif, N, H, S, weightcost, rate_vis, rate_hid, rate_w,
+                 momentum, d_err};
+    hipLaunchKernelGGL(k_rbm_sparse, dim3(1), dim3(256), 0, st, a);
+    RCK(hipGetLastError());
+    double e = 0;
+    RCK(hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st));
+    RCK(hipStreamSynchronize(st));
+    hipFree(d_err);
+    if (sq_err_out) *sq_err_out = e;
+    return FNN_OK;
+}
+
+int rbm_dense_create(int nvis, int nhid, int max_n, int precision, int device, void* stream, rbm_handle** out)
+{
+    if (!out) RFAIL(FNN_ERR_ARG, "null out");
+    *out = nullptr;
+    if (nvis < 1 || nvis > 4095 || nhid < 1 || nhid > 4095 || max_n < 1) RFAIL(FNN_ERR_ARG, "bad shape");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
+    if (device < 0 || device >= ndev) RFAIL(FNN_ERR_ARG, "device ordinal out of range");
+    rbm_handle* h = new rbm_handle();
+    h->nvis = nvis; h->nhid = nhid; h->Kp = rup(nvis + 1, 64); h->Hp = rup(nhid + 1, 64);
+    h->max_n = max_n; h->Na_max = rup(max_n, 256); h->dev = device; h->bf16 = precision == FNN_PREC_BF16;
+    h->nW = (size_t)h->Kp * h->Hp;
+    RCK(hipSetDevice(device));
+    if (stream) h->st = (hipStream_t)stream; else { RCK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking)); h->own_stream = true; }
+    const size_t ts = h->bf16 ? 2 : 4, Na = h->Na_max;
+    auto al = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, h->st); return e; };
+    RCK(al((void**)&h->Wp, h->nW * 4)); RCK(al((void**)&h->wsp, h->nW * 4));
+    RCK(al((void**)&h->slab, (size_t)h->splitk * 2 * h->nW * 4));
+    RCK(al(&h->wf, h->nW * ts)); RCK(al(&h->wtf, h->nW * ts));
+    RCK(al(&h->Xr, Na * h->Kp * ts)); RCK(al(&h->XT, Na * h->Kp * ts));
+    RCK(al(&h->hid, Na * h->Hp * ts)); RCK(al(&h->hidT, Na * h->Hp * ts)); RCK(al(&h->hs, Na * h->Hp * ts));
+    RCK(al(&h->vis, Na * h->Kp * ts)); RCK(al(&h->visT, Na * h->Kp * ts));
+    RCK(al(&h->hid2, Na * h->Hp * ts)); RCK(al(&h->hid2T, Na * h->Hp * ts));
+    RCK(hipMalloc((void**)&h->ones, (size_t)(h->Kp > h->Hp ? h->Kp : h->Hp)));
+    RCK(hipMemsetAsync(h->ones, 1, (size_t)(h->Kp > h->Hp ? h->Kp : h->Hp), h->st));
+    RCK(al((void**)&h->errpart, 256 * sizeof(double)));
+    RCK(hipStreamSynchronize(h->st));
+    *out = h;
+    return FNN_OK;
+}
+
+int rbm_dense_destroy(rbm_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    hipSetDevice(h->dev);
+    hipStreamSynchronize(h->st);
+    void* ptrs[] = {h->Wp, h->wsp, h->slab, h->wf, h->wtf, h->Xr, h->XT, h->hid, h->hidT, h->hs, h->vis, h->visT,
+                    h->hid2, h->hid2T, h->ones, h->errpart};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->own_stream) hipStreamDestroy(h->st);
+    delete h;
+    return FNN_OK;
+}
+
+int rbm_dense_set(rbm_handle* h, const float* W, const float* visbias, const float* hidbias)
+{
+    if (!h || !W || !visbias || !hidbias) RFAIL(FNN_ERR_ARG, "null pointer");
+    RCK(hipSetDevice(h->dev));
+    std::vector<float> p(h->nW, 0.f);
+    for (int r = 0; r < h->nvis; ++r) {
+        memcpy(&p[(size_t)r * h->Hp], &W[(size_t)r * h->nhid], (size_t)h->nhid * 4);
+        p[(size_t)r * h->Hp + h->nhid] = visbias[r];
+    }
+    memcpy(&p[(size_t)h->nvis * h->Hp], hidbias, (size_t)h->nhid * 4);
+    RCK(hipStreamSynchronize(h->st));
+    RCK(hipMemcpy(h->Wp, p.data(), h->nW * 4, hipMemcpyHostToDevice));
+    RCK(hipMemsetAsync(h->wsp, 0, h->nW * 4, h->st));
+    if (h->bf16) rbm_refresh<bf16_t>(h, 0, 0, 0, 0, 0, 0, 0); else rbm_refresh<float>(h, 0, 0, 0, 0, 0, 0, 0);
+    RCK(hipStreamSynchronize(h->st));
+    return FNN_OK;
+}
+
+int rbm_dense_get(rbm_handle* h, float* W, float* visbias, float* hidbias)
+{
+    if (!h || !W || !visbias || !hidbias) RFAIL(FNN_ERR_ARG, "null pointer");
+    RCK(hipSetDevice(h->dev));
+    std::vector<float> p(h->nW);
+    RCK(hipStreamSynchronize(h->st));
+    RCK(hipMemcpy(p.data(), h->Wp, h->nW * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < h->nvis; ++r) {
+        memcpy(&W[(size_t)r * h->nhid], &p[(size_t)r * h->Hp], (size_t)h->nhid * 4);
+        visbias[r] = p[(size_t)r * h->Hp + h->nhid];
+    }
+    memcpy(hidbias, &p[(size_t)h->nvis * h->Hp], (size_t)h->nhid * 4);
+    return FNN_OK;
+}
+
+int rbm_dense_cd1(rbm_handle* h, const float* X, int n, const float* unif, float weightcost, float rate_vis,
+                  float rate_hid, float rate_w, float momentum, double* sq_err_out)
+{
+    if (!h || !X || !unif) RFAIL(FNN_ERR_ARG, "null pointer");
+    if (n < 1 || n > h->max_n) RFAIL(FNN_ERR_ARG, "n must be in [1, max_n]");
+    RCK(hipSetDevice(h->dev));
+    return h->bf16 ? rbm_step<bf16_t>(h, X, n, unif, weightcost, rate_vis, rate_hid, rate_w, momentum, sq_err_out)
+                   : rbm_step<float>(h, X, n, unif, weightcost, rate_vis, rate_hid, rate_w, momentum, sq_err_out);
+}
+
+int rbm_bag_sum(const float* W0, const float* b0, int H, int64_t n_rows, const int32_t* ids, int n, int F,
+                float* out, void* stream)
+{
+    if (!W0 || !b0 || !ids || !out || n < 1) RFAIL(FNN_ERR_ARG, "bad argument");
+    const size_t nt = (size_t)n * H;
+    hipLaunchKernelGGL(k_bag_sum, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W0, b0, H, n_rows,
+                       ids, n, F, out);
+    RCK(hipGetLastError());
+    return FNN_OK;
+}
+
+int rbm_affine(const float* in, const float* W, const float* bias, int n, int a, int b, float* out, void* stream)
+{
+    if (!in || !W || !bias || !out || n < 1) RFAIL(FNN_ERR_ARG, "bad argument");
+    const size_t nt = (size_t)n * b;
+    hipLaunchKernelGGL(k_affine, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, W, bias, n, a,
+                       b, out);
+    RCK(hipGetLastError());
+    return FNN_OK;
+}
+
+int rbm_sigmoid(float* x, int64_t count, void* stream)
+{
+    if (!x || count < 1) RFAIL(FNN_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_sigmoid, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, count);
+    RCK(hipGetLastError());
+    return FNN_OK;
+}
+
+}  // extern "C"

@@ -28,6 +28,11 @@ def test_header_symbols_are_exported_and_bound(built):
     for name in declared:
         assert hasattr(lib, name), name
     assert b'gfx950' in lib.fnn_version()
+    hdr = open(os.path.join(ROOT, 'include', 'rbm_hip.h')).read()
+    declared = set(re.findall(r'\b(rbm_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_capi.RBM_SIGNATURES), declared ^ set(_capi.RBM_SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_create_validates_arguments_and_fails_loudly_without_gpu(built):
@@ -206,3 +211,25 @@ def test_synth_shapes_and_formats(tmp_path):
     assert m.k == 4 and len(m.feat_row) == 200
     tr_ids, tr_y = m.load_ids(str(tmp_path / 'd' / 'train.fm.txt'))
     assert np.array_equal(tr_ids, d['ids'][:30]) and np.array_equal(tr_y, d['y'][:30])
+
+
+# ------------------------------------------------------------------ RBM host logic
+def test_rbm_line_dicts_follow_the_reference_orders(tmp_path):
+    from deep_ctr_amd import sampling_based_gaussian_binary_rbm_sparse as gbrbm
+    from oracle import rbm_oracle as ro
+    # sparse trainer: x[id-1]=0 THEN x[id]=1, in line order (rbm_sparse.py:425-437);
+    # adjacent ids 10, 11: 11's fake (10) overwrites 10's 1
+    keys, v = ro.sparse_line_dict([10, 11, 20])
+    assert keys == [9, 10, 11, 19, 20] and v == [0, 0, 1, 0, 1]
+    # dense get_batch_x: x[id]=val THEN x[id-1]=0 (rbm_sparse.py:142-156): same outcome here
+    x = ro.dense_line_dict([10, 11, 20])
+    assert x == {10: 0, 9: 0, 11: 1, 20: 1, 19: 0}
+    # opposite order in the line: 11 first, then 10 -> sparse keeps 10 (set after), dense too
+    keys, v = ro.sparse_line_dict([11, 10])
+    assert dict(zip(keys, v)) == {10: 1, 11: 1, 9: 0}
+    p = tmp_path / 't.txt'
+    p.write_text('1 10:1 11:1 20:1\n\n0 11:1 10:1 30:0\n')
+    lines = gbrbm.parse_lines(str(p))
+    assert lines == [([10, 11, 20], [1, 1, 1]), ([11, 10, 30], [1, 1, 0])]
+    act = gbrbm.dense_active_ids(lines, 4)
+    assert sorted(a for a in act[0] if a >= 0) == [11, 20] and sorted(a for a in act[1] if a >= 0) == [10, 11]

@@ -212,3 +212,62 @@ def test_golden_vectors_reproduce(golden_dir):
 def test_demo_text_files_parse(golden_dir):
     feats, y = orc.parse_line(open(os.path.join(golden_dir, 'demo', 'train.fm.txt')).readline())
     assert len(feats) == 16 and y in (0, 1)
+
+
+# ------------------------------------------------------------------ RBM oracle (A7 / A7')
+def test_sparse_cd1_matches_loop_form_of_the_reference():
+    """An independent restatement with the reference's own scalar double loops
+    (rbm_sparse.py:340-366, 447-495) must agree with the vectorised oracle step."""
+    from oracle import rbm_oracle as ro
+    rng = np.random.RandomState(5)
+    nvis, H, S = 50, 6, 4
+    st = ro.SparseRBMState(nvis, H, S, rng)
+    st.weightstep[:] = rng.standard_normal((S, H)) * 1e-3         # a non-trivial momentum buffer
+    W, vb, hb, ws = st.W.copy(), st.visbias.copy(), st.hidbias.copy(), st.weightstep.copy()
+    keys, v = [3, 9, 10, 41], [0, 1, 0, 1]
+    draw = np.random.RandomState(9)
+    u = np.random.RandomState(9).uniform(size=(1, H))
+    err = ro.sparse_cd1_example(st, keys, v, draw)
+    hid = np.zeros(H)
+    for i in range(H):                                           # _update_hidden
+        sm = 0.0
+        for j, f in enumerate(keys):
+            sm += W[f][i] * float(v[j])
+        hid[i] = 1.0 / (1.0 + np.exp(-(sm + hb[i])))
+    poscorr = np.outer(np.array(v, float), hid)
+    posact = hid.copy()
+    hs = np.where(u[0] < hid, 1.0, np.floor(hid))
+    vis = np.array([1.0 / (1.0 + np.exp(-(np.dot(hs, W[f]) + vb[f]))) for f in keys])
+    hid2 = np.array([1.0 / (1.0 + np.exp(-(sum(W[f][i] * vis[j] for j, f in enumerate(keys)) + hb[i]))) for i in range(H)])
+    step = poscorr - np.outer(vis, hid2)
+    for j, f in enumerate(keys):
+        step[j] -= 0.0002 * W[f]
+    step *= 1e-4
+    ws2 = ws * 0.9 + step
+    for j, f in enumerate(keys):
+        np.testing.assert_allclose(st.W[f], W[f] + 2 * ws2[j], rtol=1e-13, atol=1e-16)     # applied twice
+        assert abs(st.visbias[f] - (vb[f] + (v[j] - vis[j]) * 1e-4)) < 1e-15
+    np.testing.assert_allclose(st.hidbias, hb + (posact - hid2) * 1e-4, rtol=1e-13)
+    np.testing.assert_allclose(st.weightstep, ws2, rtol=1e-13)
+    assert abs(err - ((vis - np.array(v)) ** 2).sum()) < 1e-14
+    untouched = [r for r in range(nvis) if r not in keys]
+    assert np.array_equal(st.W[untouched], W[untouched])
+
+
+def test_dense_cd1_and_lower_layers():
+    from oracle import rbm_oracle as ro
+    rng = np.random.RandomState(2)
+    W0, b0 = rng.standard_normal((30, 5)), rng.standard_normal(5)
+    W1, b1 = rng.standard_normal((5, 4)), rng.standard_normal(4)
+    dicts = [ro.dense_line_dict([3, 8]), ro.dense_line_dict([9, 10])]
+    out = ro.lower_layers([W0, b0, W1, b1], dicts)
+    pre = np.array([W0[3] + W0[8] + b0, W0[10] + b0])            # 9 was zeroed by 10's fake
+    np.testing.assert_allclose(out, 1 / (1 + np.exp(-(pre @ W1 + b1))), rtol=1e-13)   # no sigmoid in between
+    st = ro.DenseRBMState(4, 3, rng)
+    W = st.W.copy()
+    batch = rng.uniform(size=(7, 4))
+    e1 = ro.dense_cd1_batch(st, batch, np.random.RandomState(1))
+    assert e1 > 0 and st.W.shape == (4, 3) and not np.array_equal(st.W, W)
+    np.testing.assert_allclose(st.W - W, st.weightstep, rtol=1e-6, atol=1e-15)          # first step: W += momentum buffer
+    with pytest.raises(AssertionError):
+        ro.dense_cd_train(st, [W0, b0], [[3, 8]] * 4, rng, minibatch=2)               # empty last batch in the reference
