@@ -1,0 +1,167 @@
+"""`python SNN_RBM.py [advertiser] [flag]` -- the SNN-RBM script on MI355X.
+
+Script behaviour (CLI, hyper-parameters, pre-train cache, log lines, epoch loop, early stop)
+follows the reference's python/SNN_RBM.py.  Layer-wise CD-1 pre-training runs on the HIP kernels
+behind include/rbm_hip.h (`get_rbm_weights`), the fine-tune loop on FNNEngine in bag mode: the
+embedding-bag + sigmoid input layer (`get_fi_h1_y`, :238-262), the Theano graph (:105-153) and the
+per-example row updates (:285-291) are HIP kernels.
+
+Environment: DEEPCTR_DATA_DIR (default ../data), DEEPCTR_EPOCHS, DEEPCTR_PRECISION (f32 | bf16),
+DEEPCTR_XDIM (default 133465 as hard-coded at :49; `auto` = largest feature id + 1),
+DEEPCTR_LOG_DIR.
+"""
+import math
+import os
+import pickle
+import sys
+import time
+
+import numpy
+from sklearn.metrics import log_loss, mean_squared_error, roc_auc_score
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deep_ctr_amd  # noqa: E402,F401
+from deep_ctr_amd import dl_utils as ut  # noqa: E402
+from deep_ctr_amd import sampling_based_gaussian_binary_rbm_sparse as gbrbm  # noqa: E402
+from deep_ctr_amd.engine import FNNEngine  # noqa: E402
+
+
+def load_active_ids(path, n_fields=16):
+    """The parse of get_fi_h1_y / auc_rmse (:238-262, :176-186): split on single spaces, a feature
+    counts only when its value is 1.  Returns (ids int32 [N, n_fields] with -1 padding, y [N])."""
+    ids, ys = [], []
+    with open(path, 'r') as fi:
+        for line in fi:
+            if line.strip() == '':
+                continue
+            s = line.strip().replace(':', ' ').split(' ')
+            act = [int(s[f]) for f in range(1, len(s), 2) if int(s[f + 1]) == 1]
+            ids.append(act + [-1] * (n_fields - len(act)))
+            ys.append(int(s[0]))
+    return numpy.asarray(ids, dtype=numpy.int32), numpy.asarray(ys, dtype=numpy.int32)
+
+
+def run(argv):
+    srng = ut.RandomStreams(seed=234)                          # :18
+    ut.seed_global(1234)                                       # :19-21 (and the two imports before it)
+    batch_size = 1000                                          # :22-29
+    lr = 0.0006
+    lambda1 = 0.0001
+    hidden0 = 300
+    hidden1 = 300
+    hidden2 = 100
+    acti_type = 'tanh'
+    epoch = int(os.environ.get('DEEPCTR_EPOCHS', 100))
+    advertiser = '2997'
+    if len(argv) > 1:
+        advertiser = argv[1]
+    data_dir = os.environ.get('DEEPCTR_DATA_DIR', '../data')
+    train_file = os.path.join(data_dir, 'train.fm.txt')        # :32-34
+    test_file = os.path.join(data_dir, 'test.fm.txt')
+    fm_model_file = os.path.join(data_dir, 'fm.model.txt')
+    if len(argv) > 2 and advertiser == 'all':                  # :39-44
+        train_file = train_file + '.10.txt'
+    elif len(argv) > 2 and argv[2] == "mod2":
+        train_file = train_file + '.2.txt'
+    elif len(argv) > 2:
+        train_file = train_file + '.5.txt'
+    print(train_file)
+    train_size = ut.file_len(train_file)                       # :46-48
+    n_batch = train_size // batch_size
+    x_dim = 133465                                             # :49
+    dropout = 1
+    if advertiser == '2997':                                   # :52-58
+        hidden0 = 200
+        hidden1 = 300
+        hidden2 = 100
+        lr = 0.001
+        dropout = 0.98
+        lambda1 = 0
+    train_ids, train_y = load_active_ids(train_file)
+    test_ids, test_y = load_active_ids(test_file)
+    xd = os.environ.get('DEEPCTR_XDIM')
+    if xd == 'auto':
+        x_dim = int(max(train_ids.max(), test_ids.max())) + 1
+    elif xd:
+        x_dim = int(xd)
+
+    def log_p(msg, m=""):
+        ut.log_p(msg, "drop_mlp4da" + str(advertiser))
+
+    log_p('drop_mlp4da.py|ad:' + advertiser + '|drop:' + str(dropout) + '|b_size:' + str(batch_size) + ' | X:' +
+          str(x_dim) + ' | Hidden 0:' + str(hidden0) + ' | Hidden 1:' + str(hidden1) + ' | Hidden 2:' + str(hidden2) +
+          ' | L_r:' + str(lr) + ' | activation1:' + str(acti_type) + ' | lambda:' + str(lambda1))
+
+    arr = [x_dim, hidden0, hidden1, hidden2]
+    ww0, bb0 = ut.init_weight(x_dim, hidden0, 'sigmoid')       # :78-80 (consume the RNG even when a cache exists)
+    ww1, bb1 = ut.init_weight(hidden0, hidden1, 'sigmoid')
+    ww2, bb2 = ut.init_weight(hidden1, hidden2, 'sigmoid')
+
+    precision = os.environ.get('DEEPCTR_PRECISION', 'f32')
+    wfile = "rbm_" + str(advertiser) + "_.p"                   # :82-88
+    if os.path.isfile(wfile):
+        (ww0, bb0, ww1, bb1, ww2, bb2) = pickle.load(open(wfile, "rb"))
+    else:
+        ww0, bb0, ww1, bb1, ww2, bb2 = gbrbm.get_rbm_weights(train_file, arr, ncases=train_size, batch_size=100000,
+                                                             fm_model_file=fm_model_file, precision=precision)
+        pickle.dump((ww0, bb0, ww1, bb1, ww2, bb2), open(wfile, "wb"))
+
+    ww3 = ut.rng.uniform(-0.05, 0.05, hidden2)                 # :91 (drawn, then overwritten)
+    ww3 = numpy.zeros(hidden2)
+    bb3 = 0.
+
+    r1 = srng.binomial(size=(1, hidden1), n=1, p=dropout)      # :117,130 (no input mask in this script)
+    r2 = srng.binomial(size=(1, hidden2), n=1, p=dropout)
+
+    eng = FNNEngine(n_fields=train_ids.shape[1], k=0, hidden1=hidden1, hidden2=hidden2, max_batch=4096,
+                    precision=precision, acti_type=acti_type, lr=lr, lambda1=lambda1, lambda_fm=0.0, reg_all=True,
+                    mode='bag', hidden0=hidden0)
+    eng.set_table(ww0, numpy.zeros(ww0.shape[0], numpy.int32), 0.0)
+    eng.set_bag_bias(bb0)
+    eng.set_dense({'w1': ww1, 'b1': bb1, 'w2': ww2, 'b2': bb2, 'w3': ww3, 'b3': bb3})
+
+    def auc_rmse(ids, y):                                      # :162-198
+        yp = eng.predict(ids).cpu().numpy().astype(numpy.float64)
+        return roc_auc_score(y, yp), math.sqrt(mean_squared_error(y, yp)), log_loss(y, yp, labels=[0, 1])
+
+    def fmt_time(t):
+        return str(int(t / 60)) + 'm ' + str(int(t % 60)) + 's'
+
+    print("Training model:")                                   # mytrain, :269-323
+    min_err = 0
+    min_err_epoch = 0
+    times_reduce = 0
+    hist = []
+    for i in range(epoch):
+        start_time = time.time()
+        for j in range(n_batch):
+            lo = j * batch_size
+            eng.train_step(train_ids[lo:lo + batch_size], train_y[lo:lo + batch_size], r1.draw()[0], r2.draw()[0],
+                           want_loss=False)
+        eng.sync()
+        print('training: ' + fmt_time(time.time() - start_time))
+        start_time = time.time()
+        auc, rmse, ll = auc_rmse(train_ids, train_y)
+        log_p('\t\tTraining Err: \t' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
+        print('training error: ' + fmt_time(time.time() - start_time))
+        start_time = time.time()
+        auc, rmse, ll = auc_rmse(test_ids, test_y)
+        log_p('Test Err:' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
+        log_p('Test logloss:' + str(i) + '\t' + str(ll))
+        print('test error: ' + fmt_time(time.time() - start_time))
+        hist.append({'epoch': i, 'test_auc': auc, 'test_rmse': rmse, 'test_logloss': ll})
+        if auc > min_err:                                      # :314-322
+            min_err = auc
+            min_err_epoch = i
+            if times_reduce < 3:
+                times_reduce += 1
+        else:
+            times_reduce -= 1
+        if times_reduce < -2:
+            break
+    log_p('Minimal test error is ' + str(min_err) + ' , at EPOCH ' + str(min_err_epoch))
+    return hist
+
+
+if __name__ == '__main__':
+    run(sys.argv)
