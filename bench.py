@@ -138,8 +138,11 @@ def main():
         else:
             rc = lib.fnn_step_begin(*a, None, None, _capi.FNN_MEM_DEVICE)
             if rc == 0:
-                dist.all_reduce(bucket)                  # RCCL, ordered on the engine's stream
-                rc = lib.fnn_step_end(h, None)
+                work = dist.all_reduce(bucket, async_op=True)    # RCCL, ordered after the dense half
+                rc = lib.fnn_step_scatter(h)                     # sparse half overlaps the collective
+                work.wait()
+                if rc == 0:
+                    rc = lib.fnn_step_end(h, None)
         if rc != 0:
             raise RuntimeError(lib.fnn_last_error(h).decode())
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "fnn_prefetch_ids": (_i, [_vp, _vp, _i]),
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "fnn_step_scatter": (_i, [_vp]),
     "fnn_step_end": (_i, [_vp, C.POINTER(_f)]),
     "fnn_last_loss": (_i, [_vp, C.POINTER(_f)]),
     "fnn_predict": (_i, [_vp, _vp, _i, _vp, _i]),

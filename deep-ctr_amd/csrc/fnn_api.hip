@@ -71,7 +71,8 @@ struct fnn_handle {
     int32_t* st_ids = nullptr; float* st_y = nullptr; uint8_t* st_m1 = nullptr; uint8_t* st_m2 = nullptr;
     float* st_p = nullptr; float* st_x = nullptr;
     // step state
-    bool in_step = false, update_pending = false; int step_B = 0;
+    bool in_step = false, update_pending = false, scatter_pending = false, pend_have_next = false;
+    int step_B = 0, pend_Ba = 0;
     int prefetch_hits = 0, prefetch_misses = 0;
     // profiling
     bool prof = false;
@@ -210,6 +211,57 @@ void launch_sort16(fnn_handle* h, const SortArgs& so) {
     else hipLaunchKernelGGL((k_sort16<unsigned>), dim3(so.nblk), dim3(256), sort_lds_bytes<unsigned>(), h->st, so);
 }
 
+// Launches 2 and 3 of a step.  `dense`: weight gradients / slab reduce (+ update); `sparse`: the
+// sparse-row SGD of this batch and the grouping of the next one.  Single-GPU steps run both halves
+// in the same two launches; under data parallelism the dense half goes first (fnn_step_begin) so
+// that the caller's all-reduce of the bucket overlaps the sparse half (fnn_step_scatter).
+template <typename T>
+void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
+{
+    const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
+    const bool have_next = sparse && h->pend_have_next;
+    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    {
+        ProfScope ps(h, dense && sparse ? "step2" : (dense ? "step2_dense" : "step2_sparse"), h->st);
+        const WgradArgs wa = make_wgrad_args<T>(h, Ba);
+        const int nwx = dense ? wgrad_blocks(wa) : 0;
+        const int nsc = !sparse ? 0 : (h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256)
+                                              : h->F * SORT_N / 256);
+        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                    have_next ? 4 * h->F : 0, h->skeys};
+        const dim3 grid(so.nblk + nwx * h->splitk + nsc);
+        if (h->key64)
+            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 1024 * 8, h->st, so, wa, nwx,
+                               h->splitk, sa);
+        else
+            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 1024 * 4, h->st, so, wa, nwx, h->splitk, sa);
+    }
+    {
+        ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
+        const int nred = dense ? (int)((h->nw + h->nbag + 255) / 256) + 1 : 0;
+        TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
+                    h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
+                    h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
+        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                    have_next ? h->F : 0, h->skeys};
+        const dim3 grid(so.nblk + nred + (sparse ? 256 : 0));    // 256 workgroups walk the multi-chunk segments
+        const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
+        if (h->key64) {
+            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+            else hipLaunchKernelGGL((k_step3<T, false, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+        } else {
+            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+            else hipLaunchKernelGGL((k_step3<T, false, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+        }
+    }
+    if (sparse) {
+        if (have_next) { h->cur = nxt; h->sorted_ids = h->next_ids; h->sorted_B = h->next_B; }
+        else { h->sorted_ids = nullptr; h->sorted_B = 0; }
+        h->next_ids = nullptr; h->next_B = 0;
+        h->scatter_pending = false;
+    }
+}
+
 // The fast path: three role-split launches on the main stream (fnn_step_kernels.hip.h).
 template <typename T>
 int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* m1,
@@ -238,42 +290,9 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
         else hipLaunchKernelGGL(k_gx_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->gxp, h->K1p,
                                 B, h->F, h->K, gx_out_dev);
     }
-    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
-    {
-        ProfScope ps(h, "step2", h->st);
-        const WgradArgs wa = make_wgrad_args<T>(h, Ba);
-        const int nwx = wgrad_blocks(wa);
-        const int nsc = h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256) : h->F * SORT_N / 256;
-        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? 4 * h->F : 0, h->skeys};
-        const dim3 grid(so.nblk + nwx * h->splitk + nsc);
-        if (h->key64)
-            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 1024 * 8, h->st, so, wa, nwx,
-                               h->splitk, sa);
-        else
-            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 1024 * 4, h->st, so, wa, nwx, h->splitk, sa);
-    }
-    {
-        ProfScope ps(h, "step3", h->st);
-        const int nred = (int)((h->nw + h->nbag + 255) / 256) + 1;
-        TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
-                    h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
-                    h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
-        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? h->F : 0, h->skeys};
-        const dim3 grid(so.nblk + nred + 256);       // 256 workgroups walk the multi-chunk segments
-        const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
-        if (h->key64) {
-            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
-            else hipLaunchKernelGGL((k_step3<T, false, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
-        } else {
-            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
-            else hipLaunchKernelGGL((k_step3<T, false, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
-        }
-    }
-    if (have_next) { h->cur = nxt; h->sorted_ids = h->next_ids; h->sorted_B = h->next_B; }
-    else { h->sorted_ids = nullptr; h->sorted_B = 0; }
-    h->next_ids = nullptr; h->next_B = 0;
+    h->pend_Ba = Ba; h->pend_have_next = have_next;
+    if (update) launch_steps23<T>(h, true, true, true);          // dense and sparse roles share the launches
+    else { launch_steps23<T>(h, true, false, false); h->scatter_pending = true; }   // DP: sparse half deferred
     HIPCHK(h, hipGetLastError());
     return FNN_OK;
 }
@@ -792,6 +811,18 @@ int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B)
     return FNN_OK;
 }
 
+int fnn_step_scatter(fnn_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_scatter without fnn_step_begin");
+    HIPCHK(h, hipSetDevice(h->dev));
+    if (h->scatter_pending) {
+        if (h->bf16) launch_steps23<bf16_t>(h, false, true, false); else launch_steps23<float>(h, false, true, false);
+        HIPCHK(h, hipGetLastError());
+    }
+    return FNN_OK;
+}
+
 int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats)
 {
     if (!h || !dev_ptr || !n_floats) return FNN_ERR_ARG;
@@ -804,6 +835,7 @@ int fnn_step_end(fnn_handle* h, float* loss_sum_out)
     if (!h) return FNN_ERR_ARG;
     if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_end without fnn_step_begin");
     HIPCHK(h, hipSetDevice(h->dev));
+    if (h->scatter_pending) { int rc = fnn_step_scatter(h); if (rc != FNN_OK) return rc; }
     if (h->update_pending) {
         ProfScope ps(h, "update", h->st);
         if (h->bf16) launch_update<bf16_t>(h, h->bucket, h->cfg.lr); else launch_update<float>(h, h->bucket, h->cfg.lr);

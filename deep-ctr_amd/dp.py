@@ -40,7 +40,11 @@ class DataParallelFNN(object):
         """ids_local / y_local: this rank's shard.  Returns the global loss sum if asked."""
         eng = self.engine
         bucket = eng.step_begin(ids_local, y_local, mask1, mask2, b_size=global_batch)
-        self._all_reduce(bucket)
+        work = self._all_reduce(bucket)
+        if hasattr(eng, 'step_scatter'):
+            eng.step_scatter()                   # the sparse-row half runs under the collective
+        if work is not None:
+            work.wait()
         loss = eng.step_end(want_loss=want_loss)
         if want_loss:
             import torch
@@ -59,6 +63,6 @@ class DataParallelFNN(object):
         if stream is not None and bucket.is_cuda:
             import torch
             with torch.cuda.stream(stream):          # ordered after step_begin's kernels
-                self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
-        else:
-            self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
+                return self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
+        return None

@@ -214,6 +214,10 @@ class FNNEngine(object):
             self._bucket = _tensor_from_ptr(self._torch, ptr.value, n.value, self.device)
         return self._bucket
 
+    def step_scatter(self):
+        """Enqueue the sparse-row half of a begun step (overlaps an async all-reduce of the bucket)."""
+        self._ck(self.lib.fnn_step_scatter(self.h))
+
     def step_end(self, want_loss=False):
         loss = C.c_float(0.0)
         self._ck(self.lib.fnn_step_end(self.h, C.byref(loss) if want_loss else None))

@@ -146,6 +146,10 @@ int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B,
                    const uint8_t* mask1, const uint8_t* mask2, int b_size,
                    float* p_out, float* gx_out, int memkind);
 int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats);
+/* Optional, between _begin and _end: enqueue the sparse-row half of the step now, so that it
+ * overlaps an all-reduce the caller has started asynchronously; _end runs it if this was not
+ * called.  (_begin leaves the bucket complete before the sparse half is enqueued.) */
+int fnn_step_scatter(fnn_handle* h);
 int fnn_step_end(fnn_handle* h, float* loss_sum_out);
 /* Sum of the cross-entropy of the last step on this rank (synchronises). */
 int fnn_last_loss(fnn_handle* h, float* loss_sum_out);
