@@ -74,6 +74,29 @@ RBM_SIGNATURES = {
     "rbm_sigmoid": (_i, [_vp, _i64, _vp]),
 }
 
+class ipnn_cfg(C.Structure):
+    _fields_ = [("n_fields", C.c_int32), ("k", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8),
+                ("act", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32), ("lr", C.c_float),
+                ("keep_prob", C.c_float), ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
+IPNN_ACTS = {'tanh': 0, 'sigmoid': 1, 'relu': 3}
+# every symbol include/ipnn_hip.h declares
+IPNN_SIGNATURES = {
+    "ipnn_last_error": (C.c_char_p, [_vp]),
+    "ipnn_create": (_i, [C.POINTER(ipnn_cfg), C.POINTER(_vp)]),
+    "ipnn_destroy": (_i, [_vp]),
+    "ipnn_sync": (_i, [_vp]),
+    "ipnn_set_table": (_i, [_vp, _vp, _i64]),
+    "ipnn_get_rows": (_i, [_vp, _vp, _i64, _vp]),
+    "ipnn_set_b": (_i, [_vp, _f]),
+    "ipnn_get_b": (_i, [_vp, C.POINTER(_f)]),
+    "ipnn_set_layer": (_i, [_vp, _i, _vp, _vp]),
+    "ipnn_get_layer": (_i, [_vp, _i, _vp, _vp]),
+    "ipnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.POINTER(_f)]),
+    "ipnn_predict": (_i, [_vp, _vp, _i, _vp]),
+}
+
 _lib = None
 
 
@@ -93,7 +116,7 @@ def load():
             "libfnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()) + list(IPNN_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

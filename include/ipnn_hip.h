@@ -1,0 +1,70 @@
+/* ipnn_hip.h -- C ABI of the inner-product FNN family (FNN_IP_L3 / L5 / L7) in libfnn_hip.so.
+ *
+ * Replaces the TensorFlow graph of Atomu2014/deep-ctr's python/FNN_IP_L7.py (and _L3 / _L5, same
+ * pattern): `forward` :102-133 (embeddings, pair-wise inner products, z1 = [e | p | b], then
+ * l_{t+1} = dropout(act(l_t)) W_t + b_t with activation and inverted dropout BEFORE every matmul),
+ * the loss sum(sigmoid_cross_entropy_with_logits) :82-88 and the gradient step.  Categorical
+ * fields only (iPinYou shape: one id per field); optimiser: plain SGD (the reference's Adam,
+ * python/baseline.py:146, is not built).  Dropout keep-masks are INPUTS (uint8, one per element,
+ * reference column order), NULL = no dropout (`drop_out=False`).
+ *
+ * Error codes are the FNN_ERR_* of fnn_hip.h; ipnn_last_error() has the message.
+ */
+#ifndef IPNN_HIP_H
+#define IPNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPNN_ACT_TANH    0      /* python/tf_util.py:32-38 `activate` */
+#define IPNN_ACT_SIGMOID 1
+#define IPNN_ACT_RELU    3
+
+#define IPNN_MAX_HIDDEN  8
+
+typedef struct ipnn_cfg {
+    int32_t n_fields;                  /* X_feas                                             */
+    int32_t k;                         /* rank + 1: embedding row [w | v]  (FNN_IP_L7.py:66) */
+    int32_t n_hidden;                  /* 3, 5 or 7 (any 1..8)                               */
+    int32_t hidden[IPNN_MAX_HIDDEN];   /* e.g. 1000,800,600,400,200,100,50 (baseline.py:139) */
+    int32_t act;                       /* IPNN_ACT_*                                         */
+    int32_t max_batch;                 /* <= 4096                                            */
+    int32_t precision;                 /* FNN_PREC_F32 / FNN_PREC_BF16                       */
+    float   lr;
+    float   keep_prob;                 /* _reg_argv[0]                                       */
+    int32_t device;
+    void*   stream;
+} ipnn_cfg;
+
+typedef struct ipnn_handle ipnn_handle;
+
+const char* ipnn_last_error(const ipnn_handle* h);
+int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out);
+int ipnn_destroy(ipnn_handle* h);
+int ipnn_sync(ipnn_handle* h);
+
+/* HOST pointers.  table rows [n_rows, K] = concat(W, V) (fm_wv, :66); b: the scalar `fm_b`. */
+int ipnn_set_table(ipnn_handle* h, const float* rows, int64_t n_rows);
+int ipnn_get_rows(ipnn_handle* h, const int64_t* row_ids, int64_t n, float* out);
+int ipnn_set_b(ipnn_handle* h, float b);
+int ipnn_get_b(ipnn_handle* h, float* b);
+/* layer i = 1 .. n_hidden+1: W [d_{i-1}, d_i], bias [d_i]; d_0 = F*K + F(F-1)/2 + 1 (`mbd_dim`,
+ * FNN_IP_L3.py:18), d_{n_hidden+1} = 1.  Reference row order of h1_w: [e_0..e_{F-1} | pairs | b]. */
+int ipnn_set_layer(ipnn_handle* h, int layer, const float* W, const float* bias);
+int ipnn_get_layer(ipnn_handle* h, int layer, float* W, float* bias);
+
+/* DEVICE pointers: ids int32 [B, F], y f32 [B], masks[t] uint8 [B, d_t] for t = 0..n_hidden
+ * (array of n_hidden+1 device pointers held in HOST memory; NULL = no dropout).
+ * One SGD step.  logits_out [B] (device, nullable); loss_sum_out (host, nullable: synchronises). */
+int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B,
+                    const uint8_t* const* masks, float* logits_out, float* loss_sum_out);
+/* p_out [B] = sigmoid(logits) without dropout (`test_preds`, FNN_IP_L3.py:81-84). */
+int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPNN_HIP_H */

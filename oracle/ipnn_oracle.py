@@ -1,0 +1,102 @@
+"""CPU oracle for the inner-product FNN family -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+float64 NumPy restatement of the arithmetic of `python/FNN_IP_L3.py` / `FNN_IP_L5.py` /
+`FNN_IP_L7.py` (TensorFlow-0.x classes of Atomu2014/deep-ctr), SURVEY.md row A9: per-field
+embeddings e_i = [w | v] of width K = rank + 1 (:66-69 of FNN_IP_L7.py), pair-wise inner
+products p[(i, j)] for i < j in row-major upper-triangular order (:108-111), z1 = [e | p | b]
+with the bias LAST (:113-114), then for every layer  l_{t+1} = dropout(act(l_t)) W_t + b_t
+-- activation and inverted dropout BEFORE each matmul, on z1 too (:115-132) -- logits = last
+layer, loss = sum of sigmoid cross-entropy with logits (:82-88).  Categorical fields only (the 13
+numeric Criteo fields of :103 do not exist in the iPinYou shape).  Optimiser: plain SGD, the
+north_star's; the reference's Adam (baseline.py:146) is not restated.
+
+PARITY UNPINNED (no fixtures in the reference; TensorFlow absent): pinned by finite differences
+(tests/test_oracle.py).
+"""
+import numpy as np
+
+
+def act(x, name):
+    if name == 'tanh':
+        return np.tanh(x)
+    if name == 'relu':
+        return np.maximum(x, 0.0)
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def dact(x, name):
+    if name == 'tanh':
+        return 1.0 - np.tanh(x) ** 2
+    if name == 'relu':
+        return (x > 0).astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-x))
+    return s * (1 - s)
+
+
+def pairs(F):
+    return [(i, j) for i in range(F - 1) for j in range(i + 1, F)]
+
+
+def z1_of(table, b, ids):
+    """ids [B, F] (one id per field).  Returns (e [B,F,K], z1 [B, F*K + F(F-1)/2 + 1])."""
+    e = table[ids]
+    B, F, K = e.shape
+    p = np.stack([(e[:, i] * e[:, j]).sum(axis=1) for (i, j) in pairs(F)], axis=1)
+    return e, np.concatenate([e.reshape(B, F * K), p, np.full((B, 1), float(b))], axis=1)
+
+
+def forward(params, table, ids, act_name, masks=None, keep=1.0):
+    """params: {'b': scalar, 'W': [W_1..W_{L+1}], 'bias': [b_1..b_{L+1}]}.  masks: list of L+1 0/1
+    arrays (for z1 and every hidden layer) or None (drop_out=False).  Returns logits and caches."""
+    e, z1 = z1_of(table, params['b'], ids)
+    ls, As = [z1], []
+    l = z1
+    for t, (W, bias) in enumerate(zip(params['W'], params['bias'])):
+        a = act(l, act_name)
+        if masks is not None:
+            a = a * masks[t] / keep                      # tf.nn.dropout: keep, scale by 1/keep_prob
+        As.append(a)
+        l = a @ W + bias
+        ls.append(l)
+    return l[:, 0], {'e': e, 'ls': ls, 'As': As}
+
+
+def loss_and_grads(params, table, ids, y, act_name, masks=None, keep=1.0):
+    logits, c = forward(params, table, ids, act_name, masks, keep)
+    y = np.asarray(y, dtype=np.float64)
+    loss = float((np.maximum(logits, 0) - logits * y + np.log1p(np.exp(-np.abs(logits)))).sum())
+    d = (1.0 / (1.0 + np.exp(-logits)) - y)[:, None]       # d loss / d l_{L+1}
+    gW, gb = [None] * len(params['W']), [None] * len(params['W'])
+    for t in reversed(range(len(params['W']))):
+        gW[t] = c['As'][t].T @ d
+        gb[t] = d.sum(axis=0)
+        da = d @ params['W'][t].T
+        m = 1.0 if masks is None else masks[t] / keep
+        d = da * m * dact(c['ls'][t], act_name)              # d loss / d l_t   (t = 0: z1)
+    e = c['e']
+    B, F, K = e.shape
+    ge = d[:, :F * K].reshape(B, F, K).copy()
+    for n, (i, j) in enumerate(pairs(F)):
+        dp = d[:, F * K + n][:, None]
+        ge[:, i] += dp * e[:, j]
+        ge[:, j] += dp * e[:, i]
+    return loss, logits, {'W': gW, 'bias': gb, 'b': float(d[:, -1].sum()), 'e': ge}
+
+
+def sgd_step(params, table, ids, y, act_name, lr, masks=None, keep=1.0):
+    """One plain-SGD step on every variable; embedding rows of a batch add up their gradients
+    (the gradient through tf.concat / tf.slice is a sum).  Mutates params and table."""
+    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep)
+    for t in range(len(params['W'])):
+        params['W'][t] = params['W'][t] - lr * g['W'][t]
+        params['bias'][t] = params['bias'][t] - lr * g['bias'][t]
+    params['b'] = params['b'] - lr * g['b']
+    gt = np.zeros_like(table)
+    np.add.at(gt, ids, g['e'])
+    table -= lr * gt
+    return loss, logits, g
+
+
+def predict(params, table, ids, act_name):
+    logits, _ = forward(params, table, ids, act_name)
+    return 1.0 / (1.0 + np.exp(-logits))
