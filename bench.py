@@ -55,11 +55,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn'],
-                    help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows)')
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn'],
+                    help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
+                         'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
+    if args.workload == 'ipnn':
+        return bench_ipnn(args)
 
     import torch
     import deep_ctr_amd  # noqa: F401
@@ -230,6 +233,96 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+IP_HIDDEN = [1000, 800, 600, 400, 200, 100, 50]        # python/baseline.py:139 (FNN_IP_L7)
+
+
+def bench_ipnn(args):
+    """BASELINE configs[2]: FNN_IP_L7 train step (python/FNN_IP_L7.py:102-133 forward + loss + SGD),
+    16 fields, 937,670 rows of K=11, z1 = 297, hidden 1000/800/600/400/200/100/50 relu, keep_prob 0.5
+    (per-element keep-masks are inputs, resident in HBM), batch 4096, bf16 MFMA / f32 accumulate.
+    Single GPU (replicas under --gpus N are not launched: the config names 1 x MI355X)."""
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import synth
+    from deep_ctr_amd.ipnn import IPNNEngine
+    B, NB, NM = args.batch, 16, 4
+    dev = torch.device('cuda', 0)
+    sizes = synth.field_sizes_ipinyou()
+    rows = synth.fm_table(sum(sizes), K, 0.05, 1234)
+    ids_np = synth.zipf_ids(NB * B, sizes, 1.1, 1234)
+    y_np = (np.random.RandomState(99).uniform(size=NB * B) < 0.02).astype(np.float32)
+    d = [F * K + F * (F - 1) // 2 + 1] + IP_HIDDEN + [1]
+    eng = IPNNEngine(F, K, IP_HIDDEN, 'relu', max_batch=B, precision=args.precision, lr=1e-4, keep_prob=0.5)
+    rs = np.random.RandomState(1234)
+    # uniform(-.01, .01) as python/baseline.py:140 would leave relu activations ~0 after 7 layers;
+    # Glorot-scale weights keep every layer's arithmetic live (timing does not depend on the values)
+    Ws = [rs.uniform(-1, 1, (d[i], d[i + 1])).astype(np.float32) * np.float32(np.sqrt(6.0 / (d[i] + d[i + 1]))) for i in range(len(d) - 1)]
+    eng.set_params(rows, 0.0, Ws, [np.zeros(d[i + 1], np.float32) for i in range(len(d) - 1)])
+    ids = torch.as_tensor(ids_np).to(dev).contiguous()
+    y = torch.as_tensor(y_np).to(dev).contiguous()
+    g = torch.Generator(device=dev); g.manual_seed(234)
+    masks = [[(torch.rand((B, d[t]), device=dev, generator=g) < 0.5).to(torch.uint8).contiguous() for t in range(len(IP_HIDDEN) + 1)]
+             for _ in range(NM)]
+    marr = [(C.c_void_p * len(m))(*[x.data_ptr() for x in m]) for m in masks]
+    torch.cuda.synchronize(dev)
+    lib, h = eng.lib, eng.h
+
+    def step(i):
+        b = i % NB
+        rc = lib.ipnn_train_step(h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, marr[i % NM], None, None)
+        if rc != 0:
+            raise RuntimeError(lib.ipnn_last_error(h).decode())
+
+    for i in range(args.warmup):
+        step(i)
+    eng.sync(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    t_enq = time.perf_counter() - t0
+    eng.sync(); torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    loss = C.c_float()
+    lib.ipnn_train_step(h, ids.data_ptr(), y.data_ptr(), B, marr[0], None, C.byref(loss))
+    # per-segment device time (HIP events on the library's stream)
+    seg = {}
+    if hasattr(lib, 'ipnn_prof_enable'):
+        lib.ipnn_prof_enable(h, 1)
+        for i in range(min(args.steps, 50)):
+            step(i)
+        eng.sync()
+        for name in ('sort', 'ip_fwd', 'fwd', 'bwd', 'wgrad', 'ip_bwd', 'scatter', 'update'):
+            ms = C.c_double()
+            lib.ipnn_prof_get(h, name.encode(), C.byref(ms))
+            seg[name] = ms.value
+        lib.ipnn_prof_enable(h, 0)
+    prod = sum(d[i] * d[i + 1] for i in range(len(d) - 1))
+    fl = {'fwd': 2 * prod, 'bwd': 2 * (prod - d[0] * d[1]) + 2 * d[0] * d[1], 'wgrad': 2 * prod}
+    flops_ex = 6 * prod + 3 * 2 * (F * (F - 1) // 2) * K          # + inner products fwd and their two-sided bwd
+    ms_per_step = dt / args.steps * 1e3
+    peak = MFMA_PEAK_TFLOPS[args.precision]
+    roof = None
+    if seg and any(seg.get(k, 0) > 0 for k in fl):
+        dom = max(fl, key=lambda k: seg.get(k, 0.0))
+        ach = fl[dom] * B / (seg[dom] * 1e-3) / 1e12
+        roof = {'kernel': 'ipnn ' + dom + ' GEMM stack', 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': ach / peak, 'traffic': None, 'avg_launch_ms': seg[dom], 'algorithmic_per_example': fl[dom]}
+    ach_step = flops_ex * B / (ms_per_step * 1e-3) / 1e12
+    if roof is None:
+        roof = {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach_step, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': ach_step / peak, 'traffic': None, 'algorithmic_per_example': flops_ex}
+    roof['step'] = {'achieved': ach_step, 'frac': ach_step / peak, 'unit': 'TFLOP/s', 'flops_per_example': flops_ex}
+    print(json.dumps({
+        'metric': 'examples/sec', 'value': B * args.steps / dt, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': 'FNN_IP_L7 train step: 16 fields, 937670 rows, k=10, z1=297, hidden 1000/800/600/400/200/100/50 relu, '
+                               'keep_prob 0.5 (mask inputs), batch %d, SGD' % B, 'per_gpu_batch': B, 'global_batch': B,
+                   'parallelism': 'single'},
+        'train_logloss_last_step': loss.value / B, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
+        'roofline': roof, 'cpu_baseline': None, 'kernel_ms': seg}))
 
 
 def pmc_traffic(kernel):

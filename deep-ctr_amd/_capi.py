@@ -95,6 +95,8 @@ IPNN_SIGNATURES = {
     "ipnn_get_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.POINTER(_f)]),
     "ipnn_predict": (_i, [_vp, _vp, _i, _vp]),
+    "ipnn_prof_enable": (_i, [_vp, _i]),
+    "ipnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -241,7 +242,20 @@ struct ipnn_handle {
     int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr; void* skeys = nullptr;
     double* cpow1 = nullptr; bool key64 = true;
     size_t slab_stride = 0;
+    bool prof = false;                               // HIP-event timing of the step's segments
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
 };
+
+namespace {
+struct IpProf {                                      // one segment of ip_run on the handle's stream
+    ipnn_handle* h; const char* name; hipEvent_t b = nullptr, e = nullptr;
+    IpProf(ipnn_handle* h_, const char* n) : h(h_), name(n) {
+        if (!h->prof) return;
+        hipEventCreate(&b); hipEventCreate(&e); hipEventRecord(b, h->st);
+    }
+    ~IpProf() { if (!h->prof) return; hipEventRecord(e, h->st); h->prof_ev[name].emplace_back(b, e); }
+};
+}
 
 #define IHK(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return FNN_ERR_HIP; } } while (0)
 #define IFAIL(h, code, msg) do { (h)->err = (msg); return (code); } while (0)
@@ -265,15 +279,19 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const float keep = h->cfg.keep_prob, inv_keep = 1.0f / keep;
     const size_t lds_ip = (size_t)16 * (F * SLOT + h->Dp[0]) * sizeof(float);
     if (train) {
+        IpProf ps(h, "sort");
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
         if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(F), dim3(256), sort_lds_bytes<unsigned long long>(), h->st, so);
         else hipLaunchKernelGGL((k_sort16<unsigned>), dim3(F), dim3(256), sort_lds_bytes<unsigned>(), h->st, so);
     }
     {
+        IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag};
         hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0]);
     }
+    {
+    IpProf ps(h, "fwd");
     for (int t = 1; t <= L; ++t) {       // l_t = a_{t-1} W_t ; a_t = drop(act(l_t))
         EpiIpFwd<T> e{(T*)h->a[t], h->Dp[t], (T*)h->aT[t], ldT, (train && masks) ? masks[t] : nullptr,
                       (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->d[t], B};
@@ -286,7 +304,10 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         hipLaunchKernelGGL((k_gemm<T, 4, EpiIpOut<T>>), dim3(Ba / 64, h->Dp[L + 1] / 64, 1), dim3(256), 0, h->st, (const T*)h->a[L],
                            h->Dp[L], (const T*)h->wf[L], h->Dp[L], e);
     }
+    }
     if (!train) { IHK(h, hipGetLastError()); return FNN_OK; }
+    {
+    IpProf ps(h, "bwd");
     for (int t = L + 1; t >= 1; --t) {   // delta l_{t-1} from delta l_t ; then gW_t = a_{t-1}^T delta l_t
         const bool first = (t == 1);
         EpiIpBwd<T> e{first ? nullptr : (T*)h->dl[t - 2], h->Dp[t - 1], first ? nullptr : (T*)h->dlT[t - 2], ldT,
@@ -295,7 +316,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         hipLaunchKernelGGL((k_gemm<T, 4, EpiIpBwd<T>>), dim3(Ba / 64, h->Dp[t - 1] / 64, 1), dim3(256), 0, h->st, (const T*)h->dl[t - 1],
                            h->Dp[t], (const T*)h->wb[t - 1], h->Dp[t], e);
     }
+    }
     {   // all weight gradients: one problem per layer, own slab region each
+        IpProf ps(h, "wgrad");
         size_t off = 0;
         for (int t = 1; t <= L + 1; ++t) {
             WgradArgs wa;
@@ -307,16 +330,19 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         }
     }
     {
+        IpProf ps(h, "ip_bwd");
         IpBwdArgs ba{ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0]};
         hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, h->st, ba, h->dz0, h->gxp, h->gb_part);
     }
     {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
+        IpProf ps(h, "scatter");
         ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, (double)h->cfg.lr, h->table16, h->part, h->owner_cnt,
                     h->owners, SLOT};
         hipLaunchKernelGGL(k_scat1, dim3(F * SORT_N / 256), dim3(256), 0, h->st, sa);
         hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, sa);
     }
     {
+        IpProf ps(h, "update");
         size_t off = 0;
         for (int t = 1; t <= L + 1; ++t) { ip_refresh<T>(h, t, h->slab + off, h->cfg.lr); off += (size_t)h->Dp[t - 1] * h->Dp[t]; }
         hipLaunchKernelGGL(k_ip_update_b, dim3(1), dim3(256), 0, h->st, h->b, h->gb_part, Ba / 16, h->cfg.lr, h->loss_t, Ba, h->loss_dev);
@@ -399,6 +425,7 @@ int ipnn_destroy(ipnn_handle* h)
     void* ptrs[] = {h->table16, h->b, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
                     h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& kv : h->prof_ev) for (auto& p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
@@ -529,6 +556,28 @@ int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out)
     IHK(h, hipSetDevice(h->dev));
     return h->bf16 ? ip_run<bf16_t>(h, ids, nullptr, B, nullptr, nullptr, p_out, false)
                    : ip_run<float>(h, ids, nullptr, B, nullptr, nullptr, p_out, false);
+}
+
+int ipnn_prof_enable(ipnn_handle* h, int on)
+{
+    if (!h) return FNN_ERR_ARG;
+    IHK(h, hipStreamSynchronize(h->st));
+    if (on) { for (auto& kv : h->prof_ev) for (auto& p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); } h->prof_ev.clear(); }
+    h->prof = on != 0;
+    return FNN_OK;
+}
+
+int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms)
+{
+    if (!h || !which || !avg_ms) return FNN_ERR_ARG;
+    IHK(h, hipStreamSynchronize(h->st));
+    *avg_ms = 0.0;
+    auto it = h->prof_ev.find(which);
+    if (it == h->prof_ev.end() || it->second.empty()) return FNN_OK;
+    double tot = 0.0;
+    for (auto& p : it->second) { float ms = 0.f; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot += ms; }
+    *avg_ms = tot / (double)it->second.size();
+    return FNN_OK;
 }
 
 }  // extern "C"

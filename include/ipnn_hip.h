@@ -64,6 +64,12 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B,
 /* p_out [B] = sigmoid(logits) without dropout (`test_preds`, FNN_IP_L3.py:81-84). */
 int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out);
 
+/* Measurement hook (bench.py): HIP events on the handle's stream around the segments of a train
+ * step -- "sort", "ip_fwd", "fwd", "bwd", "wgrad", "ip_bwd", "scatter", "update".  enable(1) clears
+ * earlier samples; get returns the average device time of one segment in ms (0 if none). */
+int ipnn_prof_enable(ipnn_handle* h, int on);
+int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

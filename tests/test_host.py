@@ -33,6 +33,11 @@ def test_header_symbols_are_exported_and_bound(built):
     assert declared == set(_capi.RBM_SIGNATURES), declared ^ set(_capi.RBM_SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+    hdr = open(os.path.join(ROOT, 'include', 'ipnn_hip.h')).read()
+    declared = set(re.findall(r'\b(ipnn_[a-z0-9_]+)\s*\(', hdr)) - {'ipnn_cfg'}
+    assert declared == set(_capi.IPNN_SIGNATURES), declared ^ set(_capi.IPNN_SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
 
 
 def test_create_validates_arguments_and_fails_loudly_without_gpu(built):
