@@ -28,17 +28,11 @@ from deep_ctr_amd.engine import FNNEngine  # noqa: E402
 
 def load_active_ids(path, n_fields=16):
     """The parse of get_fi_h1_y / auc_rmse (:238-262, :176-186): split on single spaces, a feature
-    counts only when its value is 1.  Returns (ids int32 [N, n_fields] with -1 padding, y [N])."""
-    ids, ys = [], []
-    with open(path, 'r') as fi:
-        for line in fi:
-            if line.strip() == '':
-                continue
-            s = line.strip().replace(':', ' ').split(' ')
-            act = [int(s[f]) for f in range(1, len(s), 2) if int(s[f + 1]) == 1]
-            ids.append(act + [-1] * (n_fields - len(act)))
-            ys.append(int(s[0]))
-    return numpy.asarray(ids, dtype=numpy.int32), numpy.asarray(ys, dtype=numpy.int32)
+    counts only when its value is 1.  Returns (ids int32 [N, n_fields] with -1 padding, y [N]).
+    One native pass over the file (ctr_parse_examples, CTR_MODE_SNN_ACTIVE)."""
+    from deep_ctr_amd import ingest
+    ids, _, y = ingest.parse_examples(path, ingest.MODE_SNN_ACTIVE, None, n_fields)
+    return ids, y
 
 
 def run(argv):

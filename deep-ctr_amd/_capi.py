@@ -51,6 +51,8 @@ SIGNATURES = {
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "fnn_step_scatter": (_i, [_vp]),
+    "fnn_sparse_grad": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "fnn_step_scatter_global": (_i, [_vp, _vp, _vp, _i]),
     "fnn_step_end": (_i, [_vp, C.POINTER(_f)]),
     "fnn_last_loss": (_i, [_vp, C.POINTER(_f)]),
     "fnn_predict": (_i, [_vp, _vp, _i, _vp, _i]),
@@ -99,6 +101,23 @@ IPNN_SIGNATURES = {
     "ipnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
+_i64p = C.POINTER(_i64)
+# every symbol include/ctr_ingest.h declares (host code: native text ingestion)
+CTR_SIGNATURES = {
+    "ctr_last_error": (C.c_char_p, []),
+    "ctr_fm_model_load": (_i, [C.c_char_p, C.POINTER(C.c_char_p), _i, _i, C.POINTER(_vp)]),
+    "ctr_fm_model_free": (None, [_vp]),
+    "ctr_fm_model_n_rows": (_i64, [_vp]),
+    "ctr_fm_model_k": (_i, [_vp]),
+    "ctr_fm_model_w0": (C.c_double, [_vp]),
+    "ctr_fm_model_copy": (_i, [_vp, _vp, _vp, _vp]),
+    "ctr_fm_model_from_arrays": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp)]),
+    "ctr_count_lines": (_i, [C.c_char_p, _i, _i64p, _i64p]),
+    "ctr_parse_examples": (_i, [C.c_char_p, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _i64p]),
+    "ctr_yzx_stat": (_i, [C.c_char_p, _i, _i64p, _i64p, _i64p]),
+    "ctr_parse_yzx": (_i, [C.c_char_p, _i, _i64, _i64, _i, _vp, _vp, _vp, _i64p]),
+}
+
 _lib = None
 
 
@@ -118,7 +137,8 @@ def load():
             "libfnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()) + list(IPNN_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()) + list(IPNN_SIGNATURES.items()) + \
+            list(CTR_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

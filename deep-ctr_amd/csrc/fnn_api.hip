@@ -823,6 +823,47 @@ int fnn_step_scatter(fnn_handle* h)
     return FNN_OK;
 }
 
+int fnn_sparse_grad(fnn_handle* h, float** dev_ptr, int64_t* row_floats)
+{
+    if (!h || !dev_ptr || !row_floats) return FNN_ERR_ARG;
+    if (h->bag) FAIL(h, FNN_ERR_ARG, "fnn_sparse_grad: FNN_MODE_FM only");
+    *dev_ptr = h->gxp; *row_floats = h->K1p;
+    return FNN_OK;
+}
+
+int fnn_step_scatter_global(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_scatter_global without fnn_step_begin");
+    if (h->bag) FAIL(h, FNN_ERR_ARG, "fnn_step_scatter_global: FNN_MODE_FM only");
+    if (!ids_g || !gxp_g || B_g < 1 || B_g > h->Bmax) FAIL(h, FNN_ERR_ARG, "ids_g / gxp_g null or B_g outside [1, max_batch]");
+    if (h->cpow_n < B_g + 1) FAIL(h, FNN_ERR_STATE, "decay table shorter than the global batch");
+    HIPCHK(h, hipSetDevice(h->dev));
+    // generic kernels: one bitonic sort per field over the global (row, t) keys, then the two-level
+    // segmented update reading the gathered gradients
+    fnn_handle::SortSlot& sl = h->slot[h->cur];
+    const int N2 = sort_n2(B_g), F = h->F;
+    {
+        ProfScope ps(h, "sort_global", h->st);
+        const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
+        const dim3 blk(N2 / kpt);
+        if (kpt == 4) hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+        else if (kpt == 8) hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+        else hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+    }
+    {
+        ProfScope ps(h, "scatter_global", h->st);
+        ScatArgs sa = make_scat_args(h, sl, N2);
+        sa.gxp = gxp_g;
+        hipLaunchKernelGGL(k_scat1, dim3((unsigned)(((size_t)F * N2 + 255) / 256)), dim3(256), 0, h->st, sa);
+        hipLaunchKernelGGL(k_scat2, dim3(64), dim3(256), 0, h->st, sa);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->sorted_ids = nullptr; h->sorted_B = 0; h->next_ids = nullptr; h->next_B = 0;   // slot[cur] now holds the global grouping
+    h->scatter_pending = false;
+    return FNN_OK;
+}
+
 int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats)
 {
     if (!h || !dev_ptr || !n_floats) return FNN_ERR_ARG;

@@ -20,42 +20,39 @@ class DataFM(object):
 
     def __init__(self, fm_model_file, engine=None):
         """Parses `fm.model.txt` (python/data_fm.py:15-44): line 1 `w_0 feat_num rank`, then
-        `feat w v_1..v_rank <fieldname>:<rest>`.  Unknown field name -> KeyError, as there."""
+        `feat w v_1..v_rank <fieldname>:<rest>`.  Unknown field name -> KeyError, as there.  The
+        parse is the native multi-threaded one (include/ctr_ingest.h); the reference's dict
+        attributes `feat_field` / `feat_weights` are built from its arrays on first use."""
+        from . import ingest
         self.fm_model_file = fm_model_file
         self.engine = engine
-        self.feat_field = {}
-        self.feat_weights = {}
-        self.feat_row = {}           # feat id -> row index of the dense table (file order)
-        self.w_0 = 0
-        self.k = 0
-        self.xdim = 0
-        rows, fields = [], []
-        with open(fm_model_file, 'r') as fi:
-            head = fi.readline().strip().split()
-            self.w_0 = float(head[0])
-            self.k = int(head[2]) + 1                          # w and v
-            self.xdim = 1 + len(self.name_field) * self.k
-            k = self.k
-            for line in fi:
-                s = line.strip().split()
-                if not s:
-                    continue
-                feat = int(s[0])
-                weights = [float(v) for v in s[1:1 + k]]
-                tag = s[1 + k]
-                field = self.name_field[tag[0:tag.index(':')]]
-                if feat in self.feat_row:                     # later line overwrites, as a dict does
-                    r = self.feat_row[feat]
-                    rows[r] = weights
-                    fields[r] = field
-                else:
-                    self.feat_row[feat] = len(rows)
-                    rows.append(weights)
-                    fields.append(field)
-                self.feat_weights[feat] = weights
-                self.feat_field[feat] = field
-        self.rows = numpy.asarray(rows, dtype=numpy.float64).reshape(len(rows), self.k)
-        self.field_of_row = numpy.asarray(fields, dtype=numpy.int32)
+        names = sorted(self.name_field, key=self.name_field.get)
+        self.model = ingest.FMModel.load(fm_model_file, names)
+        self.w_0 = self.model.w0
+        self.k = self.model.k                                  # w and v
+        self.xdim = 1 + len(self.name_field) * self.k
+        self.rows, self.feat_ids, self.field_of_row = self.model.arrays()
+        self._dicts = None
+
+    def _build_dicts(self):
+        if self._dicts is None:
+            feats = self.feat_ids.tolist()
+            self._dicts = (dict(zip(feats, self.field_of_row.tolist())), dict(zip(feats, self.rows.tolist())),
+                           dict(zip(feats, range(len(feats)))))
+        return self._dicts
+
+    @property
+    def feat_field(self):                                     # python/data_fm.py:20
+        return self._build_dicts()[0]
+
+    @property
+    def feat_weights(self):                                   # python/data_fm.py:21 (parse-time weights)
+        return self._build_dicts()[1]
+
+    @property
+    def feat_row(self):
+        """feat id -> row index of the dense table (file order; a repeated id keeps its first row)."""
+        return self._build_dicts()[2]
 
     # ------------------------------------------------------------------ reference API
     def feat_layer_one_index(self, feat, l):                  # python/data_fm.py:46-47
@@ -121,17 +118,11 @@ class DataFM(object):
         return farray, ids, numpy.asarray(ys, dtype=numpy.int32)
 
     def load_ids(self, file):
-        """Whole file -> (ids int32 [N,16], y int32 [N]); blank lines skipped."""
-        ids, ys = [], []
-        with open(file, 'r') as fi:
-            for line in fi:
-                if line.strip() == '':
-                    continue
-                feats, y = self._parse(line)
-                ids.append(self.feats_to_ids(feats))
-                ys.append(y)
-        return (numpy.asarray(ids, dtype=numpy.int32).reshape(len(ys), len(self.name_field)),
-                numpy.asarray(ys, dtype=numpy.int32))
+        """Whole file -> (ids int32 [N,16], y int32 [N]); blank lines skipped.  One native pass
+        (ctr_parse_examples, CTR_MODE_FNN) instead of get_fxy per line per epoch."""
+        from . import ingest
+        ids, _, y = ingest.parse_examples(file, ingest.MODE_FNN, self.model, len(self.name_field))
+        return ids, y
 
     def table(self):
         """(rows float32 [D,K], field_of_row int32 [D], w_0) for FNNEngine.set_table."""

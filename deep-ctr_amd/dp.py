@@ -6,7 +6,10 @@ the sum of the gradients of its shards, so ONE all-reduce of ONE flat f32 bucket
 only exchange.  The dense bucket is ~0.5 MB (latency-bound on xGMI), hence a single collective,
 never one per tensor.  Embedding tables are replicated and each rank applies the sparse-row
 updates of its own shard locally (north_star); replicas' tables therefore drift apart on rows
-that several ranks touch -- reported, not hidden.  The decay constant of
+that several ranks touch -- reported, not hidden.  `sparse='exchange'` is
+the exact alternative: one all-gather of every rank's (ids, slot gradients) per
+step, after which every rank applies ALL row updates in global example order, so that replicas
+stay identical to the single-process run (the multi-GPU parity mode).  The decay constant of
 the sparse update uses the GLOBAL batch length (python/FNN_wnzh.py:304).  Dropout rows are per
 batch, not per example, so every rank must be given the same rows.
 """
@@ -24,8 +27,10 @@ class DataParallelFNN(object):
     """Wraps an engine exposing step_begin / step_end / stream (FNNEngine on a GPU).  `group` is a
     torch.distributed process group (None = default)."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, sparse='local'):
         import torch.distributed as dist
+        assert sparse in ('local', 'exchange')
+        self.sparse = sparse
         self.engine = engine
         self.dist = dist
         self.group = group
@@ -41,7 +46,9 @@ class DataParallelFNN(object):
         eng = self.engine
         bucket = eng.step_begin(ids_local, y_local, mask1, mask2, b_size=global_batch)
         work = self._all_reduce(bucket)
-        if hasattr(eng, 'step_scatter'):
+        if self.sparse == 'exchange':
+            self._exchange_sparse(ids_local, len(y_local), global_batch)
+        elif hasattr(eng, 'step_scatter'):
             eng.step_scatter()                   # the sparse-row half runs under the collective
         if work is not None:
             work.wait()
@@ -58,6 +65,31 @@ class DataParallelFNN(object):
         ids_l, y_l = self.shard(ids, y)
         return self.train_step_local(ids_l, y_l, mask1, mask2, len(y), want_loss)
 
+    def _exchange_sparse(self, ids_local, n_local, global_batch):
+        """All-gather (ids, gx') of every shard, padded to the longest shard with empty (-1) ids so
+        that the gathered order is the global example order, then apply the whole batch's row
+        updates on this rank."""
+        import torch
+        eng = self.engine
+        gx = eng.sparse_grad(n_local)                                   # [n_local, R] float
+        ids_t = ids_local if isinstance(ids_local, torch.Tensor) else torch.as_tensor(ids_local)
+        ids_t = ids_t.to(device=gx.device, dtype=torch.int32)
+        longest = -(-global_batch // self.world)
+        ids_pad = torch.full((longest, ids_t.shape[1]), -1, dtype=torch.int32, device=gx.device)
+        gx_pad = torch.zeros((longest, gx.shape[1]), dtype=gx.dtype, device=gx.device)
+        stream = getattr(eng, 'stream', None)
+        ctx = torch.cuda.stream(stream) if (stream is not None and gx.is_cuda) else _Null()
+        with ctx:                                                       # ordered after step_begin's kernels
+            ids_pad[:n_local].copy_(ids_t)
+            gx_pad[:n_local].copy_(gx)
+            ids_all = [torch.empty_like(ids_pad) for _ in range(self.world)]
+            gx_all = [torch.empty_like(gx_pad) for _ in range(self.world)]
+            self.dist.all_gather(ids_all, ids_pad, group=self.group)
+            self.dist.all_gather(gx_all, gx_pad, group=self.group)
+            ids_g = torch.cat(ids_all).contiguous()
+            gx_g = torch.cat(gx_all).contiguous()
+        eng.step_scatter_global(ids_g, gx_g)
+
     def _all_reduce(self, bucket):
         stream = getattr(self.engine, 'stream', None)
         if stream is not None and bucket.is_cuda:
@@ -66,3 +98,11 @@ class DataParallelFNN(object):
                 return self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
         return None
+
+
+class _Null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

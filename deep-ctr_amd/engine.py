@@ -218,6 +218,22 @@ class FNNEngine(object):
         """Enqueue the sparse-row half of a begun step (overlaps an async all-reduce of the bucket)."""
         self._ck(self.lib.fnn_step_scatter(self.h))
 
+    def sparse_grad(self, B):
+        """gx' [B, row_floats] float32 of the begun step (slot layout: column 16 f + l), a view of the
+        library's buffer -- what the exact data-parallel mode all-gathers."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.fnn_sparse_grad(self.h, C.byref(ptr), C.byref(n)))
+        return _tensor_from_ptr(self._torch, ptr.value, B * n.value, self.device).view(B, n.value)
+
+    def step_scatter_global(self, ids_g, gxp_g):
+        """Exact data-parallel mode: sparse-row SGD of the all-gathered global batch (ids_g [B_g, F]
+        int32, -1 = padding; gxp_g [B_g, row_floats] float32), instead of step_scatter()."""
+        torch = self._torch
+        assert ids_g.is_cuda and ids_g.dtype == torch.int32 and ids_g.is_contiguous()
+        assert gxp_g.is_cuda and gxp_g.dtype == torch.float32 and gxp_g.is_contiguous() and gxp_g.shape[0] == ids_g.shape[0]
+        self._ck(self.lib.fnn_step_scatter_global(self.h, ids_g.data_ptr(), gxp_g.data_ptr(), ids_g.shape[0]))
+        self._keep_g = (ids_g, gxp_g)
+
     def step_end(self, want_loss=False):
         loss = C.c_float(0.0)
         self._ck(self.lib.fnn_step_end(self.h, C.byref(loss) if want_loss else None))

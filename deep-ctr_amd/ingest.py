@@ -1,0 +1,125 @@
+"""Native text ingestion (include/ctr_ingest.h, host code of libfnn_hip.so): the reference's
+per-line Python parsers -- python/FNN_wnzh.py:62-84 and :224-253, python/SNN_RBM.py:238-262,
+python/sampling_based_gaussian_binary_rbm_sparse.py:142-156, python/ipinyou.py:23-65 -- as one
+multi-threaded mmap pass per file.  Errors keep the reference's exception types: ValueError for
+a malformed token, KeyError for an unknown feature or field name, IOError for a missing file."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+
+MODE_FNN, MODE_SNN_ACTIVE, MODE_PAIRS = 0, 1, 2
+_EXC = {-1: ValueError, -2: IOError, -3: ValueError, -4: KeyError, -5: IndexError}
+
+
+def n_threads():
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+def _ck(lib, rc):
+    if rc != 0:
+        raise _EXC.get(rc, RuntimeError)((lib.ctr_last_error() or b'').decode())
+
+
+class FMModel(object):
+    """Parsed `fm.model.txt` (A1) or an id map built from arrays; owns the native handle."""
+
+    def __init__(self, handle):
+        self.lib = _capi.load()
+        self.h = handle
+
+    @classmethod
+    def load(cls, path, field_names, threads=None):
+        lib = _capi.load()
+        names = (C.c_char_p * len(field_names))(*[n.encode() for n in field_names])
+        h = C.c_void_p()
+        _ck(lib, lib.ctr_fm_model_load(os.fsencode(path), names, len(field_names), threads or n_threads(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, feat_ids, field_of_row, k, n_fields):
+        lib = _capi.load()
+        fi = np.ascontiguousarray(feat_ids, dtype=np.int64)
+        fo = np.ascontiguousarray(field_of_row, dtype=np.int32)
+        h = C.c_void_p()
+        _ck(lib, lib.ctr_fm_model_from_arrays(fi.ctypes.data, fo.ctypes.data, len(fi), k, n_fields, C.byref(h)))
+        return cls(h)
+
+    @property
+    def n_rows(self):
+        return int(self.lib.ctr_fm_model_n_rows(self.h))
+
+    @property
+    def k(self):
+        return int(self.lib.ctr_fm_model_k(self.h))
+
+    @property
+    def w0(self):
+        return float(self.lib.ctr_fm_model_w0(self.h))
+
+    def arrays(self, want_rows=True):
+        """(rows float64 [n,k] or None, feat_ids int64 [n], field_of_row int32 [n]), file order."""
+        n, k = self.n_rows, self.k
+        rows = np.empty((n, k), np.float64) if want_rows else None
+        feat = np.empty(n, np.int64)
+        fo = np.empty(n, np.int32)
+        _ck(self.lib, self.lib.ctr_fm_model_copy(self.h, rows.ctypes.data if want_rows else None, feat.ctypes.data, fo.ctypes.data))
+        return rows, feat, fo
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.ctr_fm_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_lines(path, threads=None):
+    """(lines, non-blank lines) -- `file_len` of python/dl_utils.py:111-115 counts the former."""
+    lib = _capi.load()
+    nl, ne = C.c_int64(), C.c_int64()
+    _ck(lib, lib.ctr_count_lines(os.fsencode(path), threads or n_threads(), C.byref(nl), C.byref(ne)))
+    return nl.value, ne.value
+
+
+def parse_examples(path, mode, model=None, width=16, threads=None):
+    """Whole file -> (ids int32 [N, width], vals int32 [N, width] or None, y int32 [N])."""
+    lib = _capi.load()
+    threads = threads or n_threads()
+    _, n = count_lines(path, threads)
+    ids = np.empty((n, width), np.int32)
+    vals = np.empty((n, width), np.int32) if mode == MODE_PAIRS else None
+    y = np.empty(n, np.int32)
+    got = C.c_int64()
+    _ck(lib, lib.ctr_parse_examples(os.fsencode(path), mode, model.h if model is not None else None, width, threads, n,
+                                    ids.ctypes.data, vals.ctypes.data if vals is not None else None, y.ctypes.data, C.byref(got)))
+    assert got.value == n
+    return ids, vals, y
+
+
+def yzx_stat(path, threads=None):
+    """python/ipinyou.py:23-39 `stat`: (max_dim, max_fea), plus the line count."""
+    lib = _capi.load()
+    n, md, mf = C.c_int64(), C.c_int64(), C.c_int64()
+    _ck(lib, lib.ctr_yzx_stat(os.fsencode(path), threads or n_threads(), C.byref(n), C.byref(md), C.byref(mf)))
+    return md.value, mf.value, n.value
+
+
+def parse_yzx(path, max_dim, max_fea, threads=None):
+    """python/ipinyou.py:42-65 for the whole file, in file order: X_ind, X_val [n, max_fea] int64, y [n]."""
+    lib = _capi.load()
+    threads = threads or n_threads()
+    n, _ = count_lines(path, threads)
+    X_ind = np.empty((n, max_fea), np.int64)
+    X_val = np.empty((n, max_fea), np.int64)
+    y = np.empty(n, np.int64)
+    got = C.c_int64()
+    _ck(lib, lib.ctr_parse_yzx(os.fsencode(path), threads, n, max_dim, max_fea, X_ind.ctypes.data, X_val.ctypes.data,
+                               y.ctypes.data, C.byref(got)))
+    return X_ind[:got.value], X_val[:got.value], y[:got.value]

@@ -70,6 +70,22 @@ def feed_zero(X_ind, X_val, y, max_dim, max_fea):
     return X_ind[inds], X_val[inds], y[inds]
 
 
+def stat_file(path):
+    """`stat` as one native pass (ctr_yzx_stat): (max_dim, max_fea).  Unlike `stat` it does not
+    shuffle buffers, so it leaves the global NumPy RNG untouched."""
+    from . import ingest
+    md, mf, _ = ingest.yzx_stat(path)
+    return md, mf
+
+
+def load_ipinyou_file(path, max_dim, max_fea):
+    """`load_ipinyou_data` for a whole file in one native pass (ctr_parse_yzx), FILE order: the
+    reference shuffles each 10,000-line buffer with the global RNG (python/ipinyou.py:19) -- apply
+    a permutation afterwards where that order matters."""
+    from . import ingest
+    return ingest.parse_yzx(path, max_dim, max_fea)
+
+
 def to_field_ids(X_ind, X_val, field_of_row):
     """Bridge to the HIP path: padded index lists -> ids int32 [n,16] with slot = field and -1 for
     empty fields (pads have X_val == 0)."""

@@ -20,14 +20,15 @@ def _check(lib, rc):
         raise RuntimeError("rbm_hip error %d: %s" % (rc, (lib.rbm_last_error() or b'').decode()))
 
 
-def parse_lines(path):
-    """`y id:val id:val ...` split on single spaces (:423-424); returns (ids, vals) per line."""
+def parse_lines(path, width=64):
+    """`y id:val id:val ...` split on single spaces (:423-424); returns (ids, vals) per line.  The
+    token work is the native pass (ctr_parse_examples, CTR_MODE_PAIRS)."""
+    from . import ingest
+    ids, vals, _ = ingest.parse_examples(path, ingest.MODE_PAIRS, None, width)
     out = []
-    with open(path, 'r') as ins:
-        for line in ins:
-            if line.strip() != "":
-                s = line.strip().replace(':', ' ').split(' ')
-                out.append(([int(s[f]) for f in range(1, len(s), 2)], [int(s[f + 1]) for f in range(1, len(s), 2)]))
+    for a, v in zip(ids.tolist(), vals.tolist()):
+        n = a.index(-1) if -1 in a else len(a)
+        out.append((a[:n], v[:n]))
     return out
 
 

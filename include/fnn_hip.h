@@ -150,6 +150,15 @@ int fnn_dense_grad_bucket(fnn_handle* h, float** dev_ptr, int64_t* n_floats);
  * overlaps an all-reduce the caller has started asynchronously; _end runs it if this was not
  * called.  (_begin leaves the bucket complete before the sparse half is enqueued.) */
 int fnn_step_scatter(fnn_handle* h);
+/* Exact data-parallel mode (FNN_MODE_FM): the sparse-row exchange.  After _begin the slot-layout
+ * row gradients of this rank's shard sit in gx' [B, *row_floats] f32 (column 16 f + l = d cost /
+ * d row(ids[t][f])[l]); fnn_sparse_grad exposes that buffer so that the caller can all-gather it
+ * together with the ids.  fnn_step_scatter_global then applies, INSTEAD of fnn_step_scatter, the
+ * sparse-row SGD of the whole global batch in global example order (python/FNN_wnzh.py:299-306 --
+ * every replica's table stays identical to the single-process run): ids_g [B_g, F] int32 (-1 =
+ * empty / padding), gxp_g [B_g, row_floats] f32, DEVICE pointers, B_g <= max_batch. */
+int fnn_sparse_grad(fnn_handle* h, float** dev_ptr, int64_t* row_floats);
+int fnn_step_scatter_global(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g);
 int fnn_step_end(fnn_handle* h, float* loss_sum_out);
 /* Sum of the cross-entropy of the last step on this rank (synchronises). */
 int fnn_last_loss(fnn_handle* h, float* loss_sum_out);

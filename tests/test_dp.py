@@ -41,6 +41,7 @@ class OracleEngine(object):
         self.p, self.rows, self.w0, self.lr, self.lam1, self.lamfm = p, rows, w0, lr, lam1, lamfm
         self.sizes = [int(np.asarray(p[k]).size) for k in NAMES]
         self.bucket = torch.zeros(sum(self.sizes), dtype=torch.float64)
+        self.pend = None
 
     def step_begin(self, ids, y, m1, m2, b_size=0):
         x = orc.gather(self.rows, ids, self.w0)
@@ -49,10 +50,27 @@ class OracleEngine(object):
         g['w3'] = g['w3'] - 2 * self.lam1 * self.p['w3']
         g['b3'] = g['b3'] - 2 * self.lam1 * self.p['b3']
         self.bucket.copy_(torch.from_numpy(np.concatenate([np.asarray(g[k], dtype=np.float64).ravel() for k in NAMES])))
-        orc.scatter_sgd(self.rows, ids, g['x'], self.lr, self.lamfm, b_size if b_size > 0 else None)
+        self.pend = (np.asarray(ids), g['x'], b_size if b_size > 0 else None)
         return self.bucket
 
+    def step_scatter(self):
+        if self.pend is not None:
+            ids, gx, b_size = self.pend
+            orc.scatter_sgd(self.rows, ids, gx, self.lr, self.lamfm, b_size)
+            self.pend = None
+
+    # exact mode: the engine exposes gx (reference layout here; the HIP engine uses its slot layout)
+    def sparse_grad(self, B):
+        return torch.from_numpy(np.ascontiguousarray(self.pend[1][:B]))
+
+    def step_scatter_global(self, ids_g, gx_g):
+        ids_g, gx_g = ids_g.numpy(), gx_g.numpy()
+        live = ids_g[:, 0] >= 0                               # padding rows carry -1 ids
+        orc.scatter_sgd(self.rows, ids_g[live], gx_g[live], self.lr, self.lamfm, self.pend[2])
+        self.pend = None
+
     def step_end(self, want_loss=False):
+        self.step_scatter()
         flat, off = self.bucket.numpy(), 0
         for k, n in zip(NAMES, self.sizes):
             g = flat[off:off + n].reshape(np.shape(self.p[k]))
@@ -76,16 +94,16 @@ def _problem():
     return rows, ids, y, p, masks
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sparse='local', per_step=20):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     rows, ids, y, p, masks = _problem()
     eng = OracleEngine(p, rows, -1.0, 0.05, 0.01, 0.2)
-    dp = DataParallelFNN(eng)
+    dp = DataParallelFNN(eng, sparse=sparse)
     losses = []
     for step in range(2):
-        sl = slice(step * 20, (step + 1) * 20)
+        sl = slice(step * per_step, (step + 1) * per_step)
         losses.append(dp.train_step(ids[sl], y[sl], masks[step][0], masks[step][1], want_loss=True))
         if step == 0:
             snap = {'s0_' + k: np.array(eng.p[k]) for k in NAMES}
@@ -141,3 +159,31 @@ def test_two_rank_dp_matches_single_process_dense_and_shards_sparse(tmp_path):
         np.testing.assert_allclose(res['rows'], engs[rank].rows, rtol=1e-12, atol=1e-14)
         for k in NAMES:
             np.testing.assert_allclose(res[k], np.asarray(engs[rank].p[k]), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("per_step", [20, 19])          # 19: unequal shards (10 + 9), padded in the exchange
+def test_two_rank_exchange_mode_equals_the_single_process_run(tmp_path, per_step):
+    """sparse='exchange' (parity mode): all-gather of (ids, gx), every rank applies the
+    whole batch's row updates in global example order -> tables AND dense tensors of both replicas
+    equal the single-process run after every step."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'exchange', per_step), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    r1 = np.load(tmp_path / 'rank1.npz')
+    rows, ids, y, p, masks = _problem()
+    losses = []
+    for step in range(2):
+        sl = slice(step * per_step, (step + 1) * per_step)
+        x = orc.gather(rows, ids[sl], -1.0)
+        gx, _, loss, _, _ = orc.train_call(p, x, y[sl], masks[step][0], masks[step][1], 0.05, 0.01)
+        orc.scatter_sgd(rows, ids[sl], gx, 0.05, 0.2)
+        losses.append(loss)
+    for res in (r0, r1):
+        np.testing.assert_allclose(res['losses'], losses, rtol=1e-10)
+        np.testing.assert_allclose(res['rows'], rows, rtol=1e-11, atol=1e-13)
+        for k in NAMES:
+            np.testing.assert_allclose(res[k], np.asarray(p[k]), rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(r0['rows'], r1['rows'])

@@ -181,6 +181,56 @@ def test_virtual_two_rank_dp_equals_single_gpu_dense(built):
         e.close()
 
 
+def test_virtual_two_rank_exchange_mode_equals_single_gpu_tables(built):
+    """Exact data-parallel mode (fnn_sparse_grad + fnn_step_scatter_global): two engines stand for
+    two ranks, (ids, gx') of the two shards are concatenated (what the all-gather does, the shorter
+    shard padded with -1 ids), every rank applies the global batch's row updates -> BOTH tables equal
+    the single-engine full-batch step on every touched row, two steps in a row."""
+    import torch
+    rows, fo, ids, y, p, r1, r2 = make_problem(2 * 500, seed=43, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.0, lamfm=0.1)
+    full = make_engine(rows, fo, p, **kw)
+    ranks = [make_engine(rows, fo, p, **kw) for _ in range(2)]
+    for step in range(2):
+        sl = slice(step * 500, (step + 1) * 500)
+        ids_s, y_s = ids[sl], y[sl]
+        full.train_step(ids_s, y_s, r1, r2)
+        cut = [slice(0, 256), slice(256, 500)]                         # unequal shards: 256 + 244
+        buckets = [e.step_begin(ids_s[h], y_s[h], r1, r2, b_size=500) for e, h in zip(ranks, cut)]
+        dev = buckets[0].device
+        ids_g = torch.full((512, F), -1, dtype=torch.int32, device=dev)
+        gx_g = torch.zeros((512, 256), dtype=torch.float32, device=dev)
+        for r, (e, h) in enumerate(zip(ranks, cut)):
+            e.sync()
+            n = h.stop - h.start
+            ids_g[256 * r:256 * r + n] = torch.as_tensor(ids_s[h]).to(dev)
+            gx_g[256 * r:256 * r + n] = e.sparse_grad(n)
+        tot = buckets[0] + buckets[1]
+        torch.cuda.synchronize()
+        for e, b in zip(ranks, buckets):
+            b.copy_(tot)
+        torch.cuda.synchronize()
+        for e in ranks:
+            e.step_scatter_global(ids_g, gx_g)
+            e.step_end()
+            e.sync()
+    ref_rows, ref_dense = full.get_table(), full.get_dense()
+    touched = np.unique(ids[:1000])
+    change = np.abs(ref_rows[touched] - rows[touched].astype(np.float32)).max()
+    for e in ranks:
+        got = e.get_table()
+        assert np.abs(got[touched] - ref_rows[touched]).max() <= 2e-4 * change + 1e-7
+        untouched = np.setdiff1d(np.arange(rows.shape[0]), touched)
+        assert np.array_equal(got[untouched], ref_rows[untouched])
+        d = e.get_dense()
+        for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+            scale = np.abs(ref_dense[k] - p[k].astype(np.float32)).max() + 1e-12
+            assert np.abs(d[k] - ref_dense[k]).max() <= 5e-4 * scale + 1e-7, k
+    assert np.array_equal(ranks[0].get_table(), ranks[1].get_table())   # replicas stay identical
+    for e in ranks + [full]:
+        e.close()
+
+
 def test_prefetch_ids_changes_nothing(built):
     """fnn_prefetch_ids is a scheduling hint: with or without it the state after several steps is
     bitwise identical (and so is a run where the hint named a batch that never came)."""

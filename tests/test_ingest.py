@@ -1,0 +1,163 @@
+"""Native text ingestion (include/ctr_ingest.h) against oracle/ingest_oracle.py -- the reference's
+Python parsers restated -- on the committed demo files and on hand-made edge cases: blank and
+whitespace-only lines, \\r\\n and lone \\r terminators, no final newline, repeated fields, repeated
+model ids, unknown features / field names, malformed tokens, and multi-threaded cuts (every thread
+count must give the same arrays and the same first error line).  Integer work: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ingest_oracle as io
+
+import deep_ctr_amd  # noqa: F401
+from deep_ctr_amd import ingest
+from deep_ctr_amd.data_fm import DataFM
+
+NAMES = sorted(io.NAME_FIELD, key=io.NAME_FIELD.get)
+
+
+def _maps(path):
+    w0, k, fw, ff = io.parse_fm_model(path)
+    feat_row = {f: i for i, f in enumerate(fw)}
+    return w0, k, fw, ff, feat_row
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_demo_model_and_files_equal_the_python_parsers(built, golden_dir, threads):
+    demo = os.path.join(golden_dir, 'demo')
+    mpath = os.path.join(demo, 'fm.model.txt')
+    w0, k, fw, ff, feat_row = _maps(mpath)
+    m = ingest.FMModel.load(mpath, NAMES, threads=threads)
+    rows, feat, fo = m.arrays()
+    assert m.w0 == w0 and m.k == k and m.n_rows == len(fw)
+    assert feat.tolist() == list(fw)
+    assert np.array_equal(rows, np.array([fw[f] for f in fw]))          # float(): bit-exact
+    assert fo.tolist() == [ff[f] for f in fw]
+    for name in ('train.fm.txt', 'test.fm.txt'):
+        path = os.path.join(demo, name)
+        ids, _, y = ingest.parse_examples(path, ingest.MODE_FNN, m, 16, threads=threads)
+        rid, ry = io.fnn_examples(path, ff, feat_row)
+        assert np.array_equal(ids, rid) and np.array_equal(y, ry)
+        assert ingest.count_lines(path, threads) == (len(ry), len(ry))
+        a, _, ya = ingest.parse_examples(path, ingest.MODE_SNN_ACTIVE, None, 16, threads=threads)
+        ra, rya = io.snn_active(path)
+        assert np.array_equal(a, ra) and np.array_equal(ya, rya)
+        pi, pv, py_ = ingest.parse_examples(path, ingest.MODE_PAIRS, None, 16, threads=threads)
+        ri, rv, ryp = io.pairs(path)
+        assert np.array_equal(pi, ri) and np.array_equal(pv, rv) and np.array_equal(py_, ryp)
+    ypath = os.path.join(demo, 'train.yzx.txt')
+    md, mf, n = ingest.yzx_stat(ypath, threads)
+    assert (md, mf) == io.yzx_stat(ypath)
+    X_ind, X_val, y = ingest.parse_yzx(ypath, md, mf, threads)
+    rX, rV, rY = io.yzx_load(ypath, md, mf)
+    assert len(y) == n and np.array_equal(X_ind, rX) and np.array_equal(X_val, rV) and np.array_equal(y, rY)
+
+
+MODEL = ("-2.5 6 2\n"
+         "10 0.1 -0.2 3e-1 weekday:1\n"
+         "\n"
+         "11  +0.5\t1.0 2.0   hour:x:y\n"
+         "12 1 2 3 IP:9\r\n"
+         "   \n"
+         "13 .5 5. -0 IP:10\r"
+         "10 9 8 7 region:again\n"                 # repeated id: later line wins, first row kept
+         "14 inf nan 1e400 slotprice:1")           # no final newline
+
+
+def test_edge_cases_of_the_model_and_example_parsers(built, tmp_path):
+    mp = tmp_path / 'fm.model.txt'
+    mp.write_bytes(MODEL.encode())
+    w0, k, fw, ff, feat_row = _maps(str(mp))
+    for threads in (1, 4):
+        m = ingest.FMModel.load(str(mp), NAMES, threads=threads)
+        rows, feat, fo = m.arrays()
+        assert feat.tolist() == [10, 11, 12, 13, 14] == list(fw)
+        assert fo.tolist() == [4, 1, 3, 3, 15] == [ff[f] for f in fw]
+        ref = np.array([fw[f] for f in fw])
+        assert np.array_equal(rows, ref, equal_nan=True) and m.w0 == -2.5 and m.k == 3
+    ex = ("1 10:1 11:1 12:1\n"
+          "\n"
+          "0 13:1 12:1\r\n"                         # two features of field IP: the later one wins
+          " \t \n"
+          "1\t14:0   11:5\r"                        # tabs and runs of spaces (FNN reader only)
+          "0 10:1")                                 # no final newline
+    ep = tmp_path / 'train.fm.txt'
+    ep.write_bytes(ex.encode())
+    ids, _, y = ingest.parse_examples(str(ep), ingest.MODE_FNN, m, 16, threads=1)
+    rid, ry = io.fnn_examples(str(ep), ff, feat_row)
+    assert np.array_equal(ids, rid) and np.array_equal(y, ry) and len(y) == 4
+    assert ids[1, 3] == feat_row[12] and ingest.count_lines(str(ep)) == (6, 4)
+    # the SNN readers split on single spaces: line 5 is a ValueError there, as in the reference
+    with pytest.raises(ValueError, match=r'train\.fm\.txt:5'):
+        ingest.parse_examples(str(ep), ingest.MODE_SNN_ACTIVE, None, 16)
+    with pytest.raises(ValueError):
+        io.snn_active(str(ep))
+    sp = tmp_path / 'snn.txt'
+    sp.write_bytes(b"1 5:1 6:0 7:1\n0 8:2\n\n1 9:1 3:1 4:1\n")
+    a, _, ya = ingest.parse_examples(str(sp), ingest.MODE_SNN_ACTIVE, None, 4)
+    ra, rya = io.snn_active(str(sp), 4)
+    assert np.array_equal(a, ra) and np.array_equal(ya, rya) and a[0].tolist() == [5, 7, -1, -1]
+    pi, pv, _ = ingest.parse_examples(str(sp), ingest.MODE_PAIRS, None, 4)
+    ri, rv, _ = io.pairs(str(sp), 4)
+    assert np.array_equal(pi, ri) and np.array_equal(pv, rv)
+    with pytest.raises(IndexError):                         # more features than the row is wide
+        ingest.parse_examples(str(sp), ingest.MODE_PAIRS, None, 2)
+
+
+def test_errors_keep_the_reference_exception_and_name_the_first_bad_line(built, tmp_path):
+    mp = tmp_path / 'fm.model.txt'
+    mp.write_bytes(MODEL.encode())
+    m = ingest.FMModel.load(str(mp), NAMES)
+    body = "".join("1 10:1 12:1\n" for _ in range(3000))
+    bad = tmp_path / 'bad.txt'
+    bad.write_bytes((body + "0 99:1\n" + body + "x 10:1\n").encode())      # KeyError at 3001, ValueError at 6002
+    for threads in (1, 2, 7):
+        with pytest.raises(KeyError, match=r'bad\.txt:3001'):
+            ingest.parse_examples(str(bad), ingest.MODE_FNN, m, 16, threads=threads)
+    bad.write_bytes((body + "1 10:1 1.5:1\n").encode())
+    with pytest.raises(ValueError, match=r'bad\.txt:3001'):
+        ingest.parse_examples(str(bad), ingest.MODE_FNN, m, 16)
+    with pytest.raises(IOError):
+        ingest.parse_examples(str(tmp_path / 'missing.txt'), ingest.MODE_FNN, m, 16)
+    bm = tmp_path / 'badmodel.txt'
+    bm.write_bytes(b"0 1 1\n5 0.1 0.2 colour:3\n")
+    with pytest.raises(KeyError, match=r'badmodel\.txt:2.*colour'):
+        ingest.FMModel.load(str(bm), NAMES)
+    with pytest.raises(KeyError):
+        io.parse_fm_model(str(bm))
+    bm.write_bytes(b"0 1 1\n5 0.1 weekday:3\n")                         # one weight short
+    with pytest.raises(ValueError):
+        ingest.FMModel.load(str(bm), NAMES)
+    empty = tmp_path / 'empty.txt'
+    empty.write_bytes(b"")
+    ids, _, y = ingest.parse_examples(str(empty), ingest.MODE_FNN, m, 16)
+    assert ids.shape == (0, 16) and y.shape == (0,)
+
+
+def test_large_file_thread_counts_agree(built, tmp_path):
+    rng = np.random.RandomState(5)
+    n_feat = 5000
+    fields = rng.randint(0, 16, n_feat)
+    with open(tmp_path / 'fm.model.txt', 'w') as f:
+        f.write("0.5 %d 3\n" % n_feat)
+        for i in range(n_feat):
+            f.write("%d %s %s:%d\n" % (1000 + 7 * i, " ".join(repr(float(v)) for v in rng.standard_normal(4)), NAMES[fields[i]], i))
+    with open(tmp_path / 'train.fm.txt', 'w') as f:
+        for t in range(20000):
+            feats = rng.randint(0, n_feat, rng.randint(1, 17))
+            f.write("%d %s\n" % (rng.randint(0, 2), " ".join("%d:1" % (1000 + 7 * j) for j in feats)))
+            if t % 997 == 0:
+                f.write("\n")
+    d = DataFM(str(tmp_path / 'fm.model.txt'))
+    w0, k, fw, ff, feat_row = _maps(str(tmp_path / 'fm.model.txt'))
+    assert d.feat_field == ff and d.feat_row == feat_row and d.feat_weights == fw and d.w_0 == w0
+    rid, ry = io.fnn_examples(str(tmp_path / 'train.fm.txt'), ff, feat_row)
+    for threads in (1, 2, 5, 16):
+        ids, _, y = ingest.parse_examples(str(tmp_path / 'train.fm.txt'), ingest.MODE_FNN, d.model, 16, threads=threads)
+        assert np.array_equal(ids, rid) and np.array_equal(y, ry)
+    ids, y = d.load_ids(str(tmp_path / 'train.fm.txt'))
+    assert np.array_equal(ids, rid)
+    # the per-batch reference API reads the same lines (linecache, 1-based, blank lines skipped)
+    f_arr, bid, by = d.get_batch_ids(str(tmp_path / 'train.fm.txt'), 1, 50)
+    assert np.array_equal(bid, rid[:len(by)]) and np.array_equal(by, ry[:len(by)])
