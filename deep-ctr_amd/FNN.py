@@ -9,13 +9,10 @@ Differences a user can see: the data directory can be overridden with DEEPCTR_DA
 `../data`, as python/FNN_wnzh.py:28-30), DEEPCTR_EPOCHS caps the epoch count, DEEPCTR_PRECISION
 selects f32 (default; parity mode) or bf16, and logloss is logged beside AUC and RMSE.
 """
-import math
 import os
 import sys
 import time
 
-import numpy
-from sklearn.metrics import log_loss, mean_squared_error, roc_auc_score
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deep_ctr_amd  # noqa: E402,F401
@@ -92,11 +89,13 @@ def run(argv, out=None):
     train_ids, train_y = data.load_ids(train_file)             # parsed once, not per epoch
     test_ids, test_y = data.load_ids(test_file)
 
-    def get_err_bat(ids, y):                                   # :193-221
-        yp = eng.predict(ids).cpu().numpy().astype(numpy.float64)
-        auc = roc_auc_score(y, yp)
-        rmse = math.sqrt(mean_squared_error(y, yp))
-        return auc, rmse, log_loss(y, yp, labels=[0, 1])
+    train_ids_d, train_y_d = eng.to_device(train_ids, train_y)   # resident in HBM for every epoch's passes
+    test_ids_d, test_y_d = eng.to_device(test_ids, test_y)
+    train_yf_d = train_y_d.float()
+
+    def get_err_bat(ids, y):                                   # :193-221, metrics on the device (fnn_eval)
+        m = eng.evaluate(ids, y)
+        return m['auc'], m['rmse'], m['logloss']
 
     def fmt_time(t):
         return str(int(t / 60)) + 'm ' + str(int(t % 60)) + 's'
@@ -114,8 +113,8 @@ def run(argv, out=None):
             lo = j * batch_size
             if lo + 1 > train_size:
                 break
-            ids = train_ids[lo:lo + batch_size]
-            y = train_y[lo:lo + batch_size]
+            ids = train_ids_d[lo:lo + batch_size]              # device-resident slices: no per-batch copies
+            y = train_yf_d[lo:lo + batch_size]
             if j == n_batch - 1:
                 pre_step = eng.get_dense()                     # `train` returns PRE-update tensors (:298)
             eng.train_step(ids, y, r1.draw()[0], r2.draw()[0], b_size=len(y), want_loss=False)
@@ -123,12 +122,12 @@ def run(argv, out=None):
         print('training: ' + fmt_time(time.time() - start_time))
 
         start_time = time.time()
-        auc, rmse, ll = get_err_bat(train_ids, train_y)
+        auc, rmse, ll = get_err_bat(train_ids_d, train_y_d)
         log_p('\t\tTraining Err: \t' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
         print('training error: ' + fmt_time(time.time() - start_time))
 
         start_time = time.time()
-        auc, rmse, ll = get_err_bat(test_ids, test_y)
+        auc, rmse, ll = get_err_bat(test_ids_d, test_y_d)
         log_p('Test Err:' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
         log_p('Test logloss:' + str(i) + '\t' + str(ll))
         print('test error: ' + fmt_time(time.time() - start_time))

@@ -10,14 +10,12 @@ Environment: DEEPCTR_DATA_DIR (default ../data), DEEPCTR_EPOCHS, DEEPCTR_PRECISI
 DEEPCTR_XDIM (default 133465 as hard-coded at :49; `auto` = largest feature id + 1),
 DEEPCTR_LOG_DIR.
 """
-import math
 import os
 import pickle
 import sys
 import time
 
 import numpy
-from sklearn.metrics import log_loss, mean_squared_error, roc_auc_score
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deep_ctr_amd  # noqa: E402,F401
@@ -115,8 +113,8 @@ def run(argv):
     eng.set_dense({'w1': ww1, 'b1': bb1, 'w2': ww2, 'b2': bb2, 'w3': ww3, 'b3': bb3})
 
     def auc_rmse(ids, y):                                      # :162-198
-        yp = eng.predict(ids).cpu().numpy().astype(numpy.float64)
-        return roc_auc_score(y, yp), math.sqrt(mean_squared_error(y, yp)), log_loss(y, yp, labels=[0, 1])
+        m = eng.evaluate(ids, y)                               # predictions and metrics stay on the device (fnn_eval)
+        return m['auc'], m['rmse'], m['logloss']
 
     def fmt_time(t):
         return str(int(t / 60)) + 'm ' + str(int(t % 60)) + 's'

@@ -56,6 +56,7 @@ SIGNATURES = {
     "fnn_step_end": (_i, [_vp, C.POINTER(_f)]),
     "fnn_last_loss": (_i, [_vp, C.POINTER(_f)]),
     "fnn_predict": (_i, [_vp, _vp, _i, _vp, _i]),
+    "fnn_eval": (_i, [_vp, _vp, _vp, _i64, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "fnn_prof_enable": (_i, [_vp, _i]),
     "fnn_prof_reset": (_i, [_vp]),
     "fnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -97,6 +98,7 @@ IPNN_SIGNATURES = {
     "ipnn_get_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.POINTER(_f)]),
     "ipnn_predict": (_i, [_vp, _vp, _i, _vp]),
+    "ipnn_eval": (_i, [_vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ipnn_prof_enable": (_i, [_vp, _i]),
     "ipnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
 }

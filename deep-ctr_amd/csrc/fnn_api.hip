@@ -4,6 +4,8 @@
 // gfx950 only; there is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +16,7 @@
 
 #include "../../include/fnn_hip.h"
 #include "fnn_step_kernels.hip.h"
+#include "metrics.hip.h"
 
 using namespace fnn;
 
@@ -923,6 +926,46 @@ int fnn_predict(fnn_handle* h, const int32_t* ids, int B, float* p_out, int memk
         HIPCHK(h, hipMemcpyAsync(p_out, p_d, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
         return check_async(h);
     }
+    return FNN_OK;
+}
+
+int fnn_eval(fnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, int memkind, double* auc, double* rmse,
+             double* logloss, float* p_out)
+{
+    int rc = check_ready(h, 1);
+    if (rc != FNN_OK) return rc;
+    if (!ids || !y || N < 1) FAIL(h, FNN_ERR_ARG, "ids / y null or N < 1");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const bool host = memkind == FNN_MEM_HOST;
+    int32_t *ids_d = nullptr, *y_d = nullptr; float* p_d = nullptr;
+    auto cleanup = [&]() { if (host) { if (ids_d) hipFree(ids_d); if (y_d) hipFree(y_d); } if (p_d && p_d != p_out) hipFree(p_d); };
+#define EK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return FNN_ERR_HIP; } } while (0)
+    if (host) {
+        EK(hipMalloc((void**)&ids_d, (size_t)N * h->F * 4)); EK(hipMalloc((void**)&y_d, (size_t)N * 4));
+        EK(hipMemcpyAsync(ids_d, ids, (size_t)N * h->F * 4, hipMemcpyHostToDevice, h->st));
+        EK(hipMemcpyAsync(y_d, y, (size_t)N * 4, hipMemcpyHostToDevice, h->st));
+    } else { ids_d = const_cast<int32_t*>(ids); y_d = const_cast<int32_t*>(y); }
+    if (p_out && !host) p_d = p_out; else EK(hipMalloc((void**)&p_d, (size_t)N * 4));
+    for (int64_t lo = 0; lo < N; lo += h->Bmax) {
+        const int B = (int)std::min<int64_t>(h->Bmax, N - lo);
+        rc = h->bf16 ? run_step<bf16_t>(h, ids_d + lo * h->F, nullptr, B, nullptr, nullptr, false, p_d + lo, nullptr)
+                     : run_step<float>(h, ids_d + lo * h->F, nullptr, B, nullptr, nullptr, false, p_d + lo, nullptr);
+        if (rc != FNN_OK) { cleanup(); return rc; }
+    }
+    EK(hipGetLastError());
+    double out[4] = {0, 0, 0, 0};
+    std::string merr;
+    const int mrc = device_metrics(h->st, p_d, y_d, N, out, merr);
+    if (mrc == -1) { h->err = merr; cleanup(); return FNN_ERR_HIP; }
+    if (p_out && host) EK(hipMemcpy(p_out, p_d, (size_t)N * 4, hipMemcpyDeviceToHost));
+#undef EK
+    cleanup();
+    if (auc) *auc = out[0];
+    if (rmse) *rmse = out[1];
+    if (logloss) *logloss = out[2];
+    rc = check_async(h);
+    if (rc != FNN_OK) return rc;
+    if (mrc == -2) FAIL(h, FNN_ERR_RANGE, merr);
     return FNN_OK;
 }
 

@@ -14,6 +14,7 @@
 #include "../../include/fnn_hip.h"
 #include "../../include/ipnn_hip.h"
 #include "fnn_step_kernels.hip.h"
+#include "metrics.hip.h"
 
 using namespace fnn;
 
@@ -556,6 +557,33 @@ int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out)
     IHK(h, hipSetDevice(h->dev));
     return h->bf16 ? ip_run<bf16_t>(h, ids, nullptr, B, nullptr, nullptr, p_out, false)
                    : ip_run<float>(h, ids, nullptr, B, nullptr, nullptr, p_out, false);
+}
+
+int ipnn_eval(ipnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, double* auc, double* rmse, double* logloss)
+{
+    if (!h || !ids || !y || N < 1) return FNN_ERR_ARG;
+    if (!h->table16) IFAIL(h, FNN_ERR_STATE, "ipnn_set_table has not been called");
+    IHK(h, hipSetDevice(h->dev));
+    float* p_d = nullptr;
+    IHK(h, hipMalloc((void**)&p_d, (size_t)N * 4));
+    for (int64_t lo = 0; lo < N; lo += h->Bmax) {
+        const int B = (int)(N - lo < h->Bmax ? N - lo : h->Bmax);
+        const int rc = h->bf16 ? ip_run<bf16_t>(h, ids + lo * h->F, nullptr, B, nullptr, nullptr, p_d + lo, false)
+                               : ip_run<float>(h, ids + lo * h->F, nullptr, B, nullptr, nullptr, p_d + lo, false);
+        if (rc != FNN_OK) { hipFree(p_d); return rc; }
+    }
+    double out[4] = {0, 0, 0, 0};
+    std::string merr;
+    const int mrc = device_metrics(h->st, p_d, y, N, out, merr);
+    hipFree(p_d);
+    if (mrc == -1) IFAIL(h, FNN_ERR_HIP, merr);
+    if (auc) *auc = out[0];
+    if (rmse) *rmse = out[1];
+    if (logloss) *logloss = out[2];
+    const int rc = ipnn_sync(h);
+    if (rc != FNN_OK) return rc;
+    if (mrc == -2) IFAIL(h, FNN_ERR_RANGE, merr);
+    return FNN_OK;
 }
 
 int ipnn_prof_enable(ipnn_handle* h, int on)

@@ -83,6 +83,10 @@ class FNNEngine(object):
             t = torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
         return t
 
+    def to_device(self, ids, y):
+        """(ids int32 [N,F], y int32 [N]) as resident device tensors (for evaluate / train slices)."""
+        return self._dev(ids, self._torch.int32), self._dev(y, self._torch.int32)
+
     def _enter(self):
         self.stream.wait_stream(self._torch.cuda.current_stream(self.device))
 
@@ -257,6 +261,24 @@ class FNNEngine(object):
             self._ck(self.lib.fnn_predict(self.h, ids_t[lo:hi].data_ptr(), hi - lo, out[lo:hi].data_ptr(),
                                           _capi.FNN_MEM_DEVICE))
         self._leave()
+        return out
+
+    def evaluate(self, ids, y, want_p=False):
+        """A10 (python/FNN_wnzh.py:193-221): predict every example and compute AUC / RMSE / logloss
+        on the device (fnn_eval).  Returns {'auc', 'rmse', 'logloss'[, 'p']}.  One class only ->
+        FNNError(FNN_ERR_RANGE), as roc_auc_score raises."""
+        torch = self._torch
+        ids_t, y_t = self._dev(ids, torch.int32), self._dev(y, torch.int32)
+        n = ids_t.shape[0]
+        p = torch.empty(n, dtype=torch.float32, device=self.device) if want_p else None
+        auc, rmse, ll = C.c_double(), C.c_double(), C.c_double()
+        self._enter()
+        self._ck(self.lib.fnn_eval(self.h, ids_t.data_ptr(), y_t.data_ptr(), n, _capi.FNN_MEM_DEVICE, C.byref(auc),
+                                   C.byref(rmse), C.byref(ll), p.data_ptr() if want_p else None))
+        self._leave()
+        out = {'auc': auc.value, 'rmse': rmse.value, 'logloss': ll.value}
+        if want_p:
+            out['p'] = p
         return out
 
     # ------------------------------------------------------------------ profiling hook

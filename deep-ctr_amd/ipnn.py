@@ -109,6 +109,15 @@ class IPNNEngine(object):
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return out
 
+    def evaluate(self, ids, y):
+        """python/baseline.py:382-437: predictions + AUC / RMSE / logloss on the device (ipnn_eval)."""
+        torch = self._torch
+        ids_t, y_t = self._dev(ids, torch.int32), self._dev(y, torch.int32)
+        auc, rmse, ll = C.c_double(), C.c_double(), C.c_double()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._ck(self.lib.ipnn_eval(self.h, ids_t.data_ptr(), y_t.data_ptr(), ids_t.shape[0], C.byref(auc), C.byref(rmse), C.byref(ll)))
+        return {'auc': auc.value, 'rmse': rmse.value, 'logloss': ll.value}
+
     def sync(self):
         self._ck(self.lib.ipnn_sync(self.h))
 

@@ -166,6 +166,15 @@ int fnn_last_loss(fnn_handle* h, float* loss_sum_out);
 /* A4': p_out [B] = predict(x) -- no masks, no rescale (python/FNN_wnzh.py:183). */
 int fnn_predict(fnn_handle* h, const int32_t* ids, int B, float* p_out, int memkind);
 
+/* A10: one evaluation pass (python/FNN_wnzh.py:193-221 get_err_bat; python/SNN_RBM.py:162-198):
+ * predict all N examples (any N; internally in max_batch chunks, predictions stay in HBM), then
+ * roc_auc_score, sqrt(mean_squared_error) and log_loss (python/baseline.py:427-429) on the device.
+ * ids [N, F] int32, y [N] int32 labels; p_out [N] float32 or NULL; metrics are HOST doubles.
+ * Only one class in y: FNN_ERR_RANGE (the reference's roc_auc_score raises ValueError); rmse and
+ * logloss are still written. */
+int fnn_eval(fnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, int memkind,
+             double* auc, double* rmse, double* logloss, float* p_out);
+
 /* Timing hook for bench.py: average device time (ms) of the kernel named
  * `which` ("gather", "fwd1", "fwd2", "head", "bwd1", "gx", "wgrad", "reduce",
  * "update", "sort", "scatter", "finalize") over the steps since the last

@@ -64,6 +64,11 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B,
 /* p_out [B] = sigmoid(logits) without dropout (`test_preds`, FNN_IP_L3.py:81-84). */
 int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out);
 
+/* Evaluation pass (python/baseline.py:382-437 `test`): predict all N examples (DEVICE ids [N, F]
+ * int32, y [N] int32; chunks of max_batch), then AUC / RMSE / logloss on the device.  Metrics are
+ * HOST doubles.  One class only: FNN_ERR_RANGE. */
+int ipnn_eval(ipnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, double* auc, double* rmse, double* logloss);
+
 /* Measurement hook (bench.py): HIP events on the handle's stream around the segments of a train
  * step -- "sort", "ip_fwd", "fwd", "bwd", "wgrad", "ip_bwd", "scatter", "update".  enable(1) clears
  * earlier samples; get returns the average device time of one segment in ms (0 if none). */

@@ -626,3 +626,30 @@ def test_snn_full_shape_reproducible(built):
         if r in untouched:
             assert np.array_equal(res[0][2][i], ww0[r])
     assert not np.array_equal(res[0][0], ww0[np.unique(ids)])
+
+
+# ------------------------------------------------------------------ A10: evaluation pass on the device
+def test_eval_metrics_equal_sklearn(built):
+    """fnn_eval: predictions of 9,001 examples (three max_batch chunks, ragged tail, many exact ties
+    from repeated examples) -> AUC / RMSE / logloss on the device against sklearn (the metric
+    oracle of python/FNN_wnzh.py:219-220, python/baseline.py:427-429) on the same float32 predictions."""
+    from sklearn.metrics import log_loss, mean_squared_error, roc_auc_score
+    rows, fo, ids, y, p, r1, r2 = make_problem(3000, seed=77)
+    p['w3'] = np.random.RandomState(5).uniform(-0.5, 0.5, H2)
+    ids = np.concatenate([ids, ids, ids, ids[:1]])                       # every example three times: tie groups
+    rng = np.random.RandomState(6)
+    yy = (rng.uniform(size=len(ids)) < 0.3).astype(np.int32)
+    eng = make_engine(rows, fo, p, max_batch=4096)
+    m = eng.evaluate(ids, yy, want_p=True)
+    pp = m['p'].cpu().numpy()
+    np.testing.assert_array_equal(pp, eng.predict(ids).cpu().numpy())
+    p64 = pp.astype(np.float64)
+    assert abs(m['auc'] - roc_auc_score(yy, p64)) < 1e-12
+    assert abs(m['rmse'] - np.sqrt(mean_squared_error(yy, p64))) < 1e-12
+    assert abs(m['logloss'] - log_loss(yy, p64, labels=[0, 1])) < 1e-12
+    m2 = eng.evaluate(ids, yy)
+    assert (m2['auc'], m2['rmse'], m2['logloss']) == (m['auc'], m['rmse'], m['logloss'])    # bitwise reproducible
+    from deep_ctr_amd.engine import FNNError
+    with pytest.raises(FNNError):                                           # roc_auc_score: ValueError
+        eng.evaluate(ids[:100], np.zeros(100, np.int32))
+    eng.close()
