@@ -103,6 +103,14 @@ IPNN_SIGNATURES = {
     "ipnn_prof_get": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
+# every symbol include/dae_hip.h declares
+DAE_SIGNATURES = {
+    "dae_last_error": (C.c_char_p, []),
+    "dae_sparse_epoch": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, C.POINTER(C.c_double), _vp]),
+    "dae_dense_epoch": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, C.POINTER(C.c_double), _vp]),
+    "dae_bag_cumsum_sigmoid": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
+}
+
 _i64p = C.POINTER(_i64)
 # every symbol include/ctr_ingest.h declares (host code: native text ingestion)
 CTR_SIGNATURES = {
@@ -140,7 +148,7 @@ def load():
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()) + list(IPNN_SIGNATURES.items()) + \
-            list(CTR_SIGNATURES.items()):
+            list(CTR_SIGNATURES.items()) + list(DAE_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,147 @@
+"""GPU parity of the SNN-DAE pre-training kernels (row N2: sparse_da / da of the reference's
+python/sampling_based_denosing_autoencoder.py) against oracle/dae_oracle.py through the C ABI of
+include/dae_hip.h.  f32 arithmetic vs the float64 oracle over thousands of sequential SGD steps:
+tolerances are relative to the size of the parameter CHANGE."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dae_oracle as do
+
+import deep_ctr_amd  # noqa: F401
+from deep_ctr_amd import dl_utils, synth
+from deep_ctr_amd import sampling_based_denosing_autoencoder as da
+
+pytestmark = pytest.mark.gpu
+
+
+def make_lines(tmp_path, n=200, n_rows=300, seed=3):
+    """16 ascending feature ids per line (field-sorted, as iPinYou lines are)."""
+    sizes = synth.field_sizes_tiny(n_rows)
+    ids = synth.zipf_ids(n, sizes, 1.1, seed)
+    feats = 3 * ids + 2
+    path = tmp_path / 'train.fm.txt'
+    with open(path, 'w') as f:
+        for t in range(n):
+            f.write('%d ' % (t % 2) + ' '.join('%d:1' % v for v in feats[t]) + '\n')
+    return str(path), 3 * sum(sizes) + 3
+
+
+def test_sampled_visibles_replay_the_reference_stream(built, tmp_path):
+    path, x_dim = make_lines(tmp_path, n=50)
+    lines = do.parse(path)
+    rs, ro_ = np.random.RandomState(5), np.random.RandomState(5)
+    idx, x = da.sampled_visibles(rs, lines, 32)
+    for n, (ids, vals) in enumerate(lines):
+        xs, ix = do.sample_negatives(ro_, ids, vals)
+        assert idx[n].tolist() == ix and x[n].tolist() == [float(v) for v in xs]
+    assert rs.random_sample() == ro_.random_sample()                   # streams stay aligned
+    # a non-ascending line takes the general path and still agrees
+    lines2 = [([9, 4, 30] + list(range(40, 53)), [1] * 16)]
+    rs, ro_ = np.random.RandomState(6), np.random.RandomState(6)
+    try:
+        want = do.sample_negatives(ro_, *lines2[0])
+    except Exception:
+        want = None
+    if want is not None and len(want[1]) == 32:
+        idx, x = da.sampled_visibles(rs, lines2, 32)
+        assert idx[0].tolist() == want[1]
+
+
+def test_get_da_weights_matches_oracle(built, tmp_path):
+    path, x_dim = make_lines(tmp_path)
+    arr = [x_dim, 40, 24, 12]
+    res = da.get_da_weights(path, arr, ncases=200)
+    lines = do.parse(path)
+    ref = do.get_da_weights(lines, arr)
+    assert [r.shape for r in res] == [(x_dim, 40), (40,), (40, 24), (24,), (24, 12), (12,)]
+    np.testing.assert_allclose(res[0], ref[0], rtol=1e-6, atol=1e-7)        # Q1: the un-trained table (f32 round trip)
+    assert np.abs(res[1] - ref[1]).max() <= 2e-3 * np.abs(ref[1]).max() + 1e-6      # hidden bias (started at 0)
+    rs = np.random.RandomState(123); rs.randint(2 ** 30)
+    for kW, kb, (row, col) in ((2, 3, (40, 24)), (4, 5, (24, 12))):
+        W_init = rs.uniform(low=-4 * np.sqrt(6. / (row + col)), high=4 * np.sqrt(6. / (row + col)), size=(row, col))
+        rs = np.random.RandomState(123); rs.randint(2 ** 30)
+        dW = np.abs(ref[kW] - W_init).max()
+        assert np.abs(res[kW] - ref[kW]).max() <= 5e-3 * dW + 1e-6, kW
+        assert np.abs(res[kb] - ref[kb]).max() <= 5e-3 * np.abs(ref[kb]).max() + 1e-6, kb
+
+
+@pytest.mark.parametrize("row,col", [(200, 300), (300, 100), (100, 100)])
+def test_dense_epoch_at_the_reference_shapes(built, row, col):
+    """The register tilings used for H0 = 200 -> H1 = 300 -> H2 = 100 (python/SNN_DAE.py:42-45): 300
+    online steps against the oracle's da_grads; skip_last leaves the state before the last step."""
+    import ctypes as C
+    import torch
+    from deep_ctr_amd import _capi
+    lib = _capi.load()
+    rng = np.random.RandomState(row + col)
+    N = 300
+    X = rng.uniform(0.05, 0.95, (N, row))
+    b = 4 * np.sqrt(6. / (row + col))
+    W0 = rng.uniform(-b, b, (row, col)).astype(np.float32).astype(np.float64)
+    W, bh, bv = W0.copy(), np.zeros(col), np.zeros(row)
+    X32 = X.astype(np.float32)
+    costs = 0.0
+    for n in range(N):
+        c, gW, dy, d = do.da_grads(W, bh, bv, X32[n].astype(np.float64))
+        costs += c
+        if n == N - 1:
+            break
+        W, bh, bv = W - 0.1 * gW, bh - 0.1 * dy, bv - 0.1 * d
+    dev = torch.device('cuda', 0)
+    Wd = torch.as_tensor(W0.astype(np.float32)).to(dev).contiguous()
+    bhd = torch.zeros(col, dtype=torch.float32, device=dev)
+    bvd = torch.zeros(row, dtype=torch.float32, device=dev)
+    Xd = torch.as_tensor(X32).to(dev).contiguous()
+    cost = C.c_double()
+    rc = lib.dae_dense_epoch(Wd.data_ptr(), bhd.data_ptr(), bvd.data_ptr(), Xd.data_ptr(), N, row, col, 0.1, 1, C.byref(cost),
+                             torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, lib.dae_last_error()
+    dW = np.abs(W - W0).max()
+    assert np.abs(Wd.cpu().numpy() - W).max() <= 2e-3 * dW + 1e-6
+    assert np.abs(bhd.cpu().numpy() - bh).max() <= 2e-3 * np.abs(bh).max() + 1e-6
+    assert np.abs(bvd.cpu().numpy() - bv).max() <= 2e-3 * np.abs(bv).max() + 1e-6
+    assert abs(cost.value - costs) <= 1e-4 * abs(costs)
+    # shapes no tiling holds are refused, not mis-computed
+    assert lib.dae_dense_epoch(Wd.data_ptr(), bhd.data_ptr(), bvd.data_ptr(), Xd.data_ptr(), N, 400, 400, 0.1, 0, None, None) != 0
+
+
+def test_snn_dae_script_on_demo_tracks_oracle(built, golden_dir, tmp_path, monkeypatch):
+    """`python SNN_DAE.py` end to end on the demo set: autoencoder pre-training (cached in
+    dropda_2997_.p) then one fine-tune epoch, against the same flow on the float64 oracles."""
+    import importlib.util
+    from oracle import fnn_oracle as orc
+    from sklearn.metrics import log_loss, roc_auc_score
+    demo = os.path.join(golden_dir, 'demo')
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('DEEPCTR_DATA_DIR', demo)
+    monkeypatch.setenv('DEEPCTR_EPOCHS', '1')
+    monkeypatch.setenv('DEEPCTR_XDIM', 'auto')
+    monkeypatch.setattr(dl_utils, 'log_path', str(tmp_path / 'log'))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('snn_dae_script', os.path.join(root, 'deep-ctr_amd', 'SNN_DAE.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.run(['SNN_DAE.py'])
+    assert (tmp_path / 'dropda_2997_.p').exists() and len(hist) == 1
+
+    from deep_ctr_amd import SNN_RBM
+    tr_ids, tr_y = SNN_RBM.load_active_ids(os.path.join(demo, 'train.fm.txt'))
+    te_ids, te_y = SNN_RBM.load_active_ids(os.path.join(demo, 'test.fm.txt'))
+    x_dim = int(max(tr_ids.max(), te_ids.max())) + 1
+    H0, H1, H2 = 200, 300, 100
+    lines = do.parse(os.path.join(demo, 'train.fm.txt'))
+    ww0, bb0, ww1, bb1, ww2, bb2 = do.get_da_weights(lines, [x_dim, H0, H1, H2], num_feats=16)
+    p = {'w1': ww1.copy(), 'b1': bb1.copy(), 'w2': ww2.copy(), 'b2': bb2.copy(), 'w3': np.zeros(H2), 'b3': 0.0}
+    ms = orc.TheanoMaskStream(H1, H2, 0.99, has_r0=False)
+    n_batch = len(tr_y) // 1000
+    for j in range(n_batch):
+        r1, r2 = ms.next()
+        orc.snn_train_step(p, ww0, bb0, tr_ids[j * 1000:(j + 1) * 1000], tr_y[j * 1000:(j + 1) * 1000].astype(np.float64), r1, r2,
+                           0.0005, 0.0)
+    pte = orc.snn_predict(p, ww0, bb0, te_ids)
+    auc, ll = roc_auc_score(te_y, pte), log_loss(te_y, pte, labels=[0, 1])
+    print("SNN-DAE demo: auc %.6f vs %.6f, logloss %.6f vs %.6f" % (hist[0]['test_auc'], auc, hist[0]['test_logloss'], ll))
+    assert abs(hist[0]['test_auc'] - auc) <= 2e-3
+    assert abs(hist[0]['test_logloss'] - ll) <= 2e-4

@@ -34,6 +34,11 @@ def test_header_symbols_are_exported_and_bound(built):
     for name in declared:
         assert hasattr(lib, name), name
     hdr = open(os.path.join(ROOT, 'include', 'ipnn_hip.h')).read()
+    hdr_d = open(os.path.join(ROOT, 'include', 'dae_hip.h')).read()
+    declared_d = set(re.findall(r'\b(dae_[a-z0-9_]+)\s*\(', hdr_d))
+    assert declared_d == set(_capi.DAE_SIGNATURES), declared_d ^ set(_capi.DAE_SIGNATURES)
+    for name in declared_d:
+        assert hasattr(lib, name), name
     hdr_c = open(os.path.join(ROOT, 'include', 'ctr_ingest.h')).read()
     declared_c = set(re.findall(r'\b(ctr_[a-z0-9_]+)\s*\(', hdr_c))
     assert declared_c == set(_capi.CTR_SIGNATURES), declared_c ^ set(_capi.CTR_SIGNATURES)

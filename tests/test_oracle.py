@@ -271,3 +271,37 @@ def test_dense_cd1_and_lower_layers():
     np.testing.assert_allclose(st.W - W, st.weightstep, rtol=1e-6, atol=1e-15)          # first step: W += momentum buffer
     with pytest.raises(AssertionError):
         ro.dense_cd_train(st, [W0, b0], [[3, 8]] * 4, rng, minibatch=2)               # empty last batch in the reference
+
+
+# ------------------------------------------------------------------ N2: denoising autoencoders
+def test_dae_oracle_gradients_and_quirks(tmp_path):
+    """oracle/dae_oracle.py: finite differences of the tied-weight dA step; Q1 (sparse_da returns the
+    un-trained table), Q2 (state before the last update), Q3 (running sum over hidden units)."""
+    from oracle import dae_oracle as do
+    rng = np.random.RandomState(0)
+    W = rng.standard_normal((7, 5)) * 0.3; b = rng.standard_normal(5) * 0.1; bv = rng.standard_normal(7) * 0.1
+    x = rng.uniform(0.1, 0.9, 7)
+    c, gW, dy, d = do.da_grads(W, b, bv, x)
+    eps = 1e-6
+    for (i, j) in ((0, 0), (3, 2), (6, 4)):
+        Wp, Wm = W.copy(), W.copy(); Wp[i, j] += eps; Wm[i, j] -= eps
+        assert abs((do.da_cost(Wp, b, bv, x)[0] - do.da_cost(Wm, b, bv, x)[0]) / (2 * eps) - gW[i, j]) < 1e-7
+    for j in (0, 4):
+        bp, bm = b.copy(), b.copy(); bp[j] += eps; bm[j] -= eps
+        assert abs((do.da_cost(W, bp, bv, x)[0] - do.da_cost(W, bm, bv, x)[0]) / (2 * eps) - dy[j]) < 1e-7
+    for i in (0, 6):
+        vp, vm = bv.copy(), bv.copy(); vp[i] += eps; vm[i] -= eps
+        assert abs((do.da_cost(W, b, vp, x)[0] - do.da_cost(W, b, vm, x)[0]) / (2 * eps) - d[i]) < 1e-7
+    lines = [([3 * i + 2 + 50 * t for i in range(4)], [1, 1, 0, 1]) for t in range(5)]
+    table, b_pre, st = do.sparse_da(8, 6, lines, sparse_len=300, epochs=2)
+    rs = np.random.RandomState(123); rs.randint(2 ** 30)
+    rs.uniform(size=(8, 6)); rs.uniform(size=(300, 6))
+    bound = 4 * np.sqrt(6. / (300 + 6))
+    assert np.array_equal(table, rs.uniform(low=-bound, high=bound, size=(300, 6)))          # Q1
+    assert not np.array_equal(b_pre, st['b']) and np.abs(st['b']).max() > 0                   # Q2
+    res = [table, b_pre]
+    h = do.propagate(res, lines[0][0])
+    bag = sum(table[r] for r in lines[0][0])
+    np.testing.assert_allclose(h, do.sigmoid(np.cumsum(bag) + b_pre))                         # Q3
+    Wl, bl, st2 = do.da(6, 4, lines, res, epochs=1)
+    assert not np.array_equal(Wl, st2['W'])                                                   # Q2 again
