@@ -160,6 +160,9 @@ __global__ __launch_bounds__(1024) void k_dae_dense(const DenseArgs a)
 #pragma unroll
         for (int c = 0; c < CPL; ++c) yv[c] = s_y[l + 64 * c];
         float cw = 0.f;
+        float p[CPL];                                             // partial of d W over this wave's rows
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) p[c] = 0.f;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {                           // z_i = sigmoid(W[i,:] . y + b'_i): a wave reduction
             float acc = 0.f;
@@ -168,24 +171,15 @@ __global__ __launch_bounds__(1024) void k_dae_dense(const DenseArgs a)
             acc = wave_sum(acc);
             const int i = r0 + r;
             const float xr = sx[i], zi = sigm(acc + s_bv[i]);
-            const float d = i < row ? zi - xr : 0.f;
+            const float d = i < row ? zi - xr : 0.f;              // the same value in every lane of the wave
             cw += i < row ? xent(xr, zi) : 0.f;
-            if (l == 0) s_d[i] = d;
+            if (l == 0) s_d[i] = d;                               // read back only after the next barrier
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) p[c] = fmaf(d, Wr[r][c], p[c]);
         }
         cost += (double)cw;
-        {   // partial of d W over this wave's rows (s_d of these rows was written by this wave)
-            float p[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) p[c] = 0.f;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const float d = s_d[r0 + r];
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) p[c] = fmaf(d, Wr[r][c], p[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) s_part[w][l + 64 * c] = p[c];
-        }
+        for (int c = 0; c < CPL; ++c) s_part[w][l + 64 * c] = p[c];
         if (tid < RP) s_x[(n & 1) ^ 1][tid] = xn;
         __syncthreads();
         const bool upd = !(a.skip_last && n + 1 == a.N);

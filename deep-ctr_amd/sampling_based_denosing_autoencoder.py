@@ -109,8 +109,9 @@ def get_da_weights(file, arr, ncases, num_feats=16, batch_size=100000, epochs=3,
                 act[n, :len(ids)] = ids
             X = torch.empty((N, col), dtype=torch.float32, device=dev)
             b0_d = t32(results[1])
-            _check(lib, lib.dae_bag_cumsum_sigmoid(tab_d.data_ptr(), b0_d.data_ptr(), col, sparse_len,
-                                                   torch.as_tensor(act).to(dev).data_ptr(), N, n_fields, X.data_ptr(), st))
+            act_d = torch.as_tensor(act).to(dev)
+            _check(lib, lib.dae_bag_cumsum_sigmoid(tab_d.data_ptr(), b0_d.data_ptr(), col, sparse_len, act_d.data_ptr(), N,
+                                                   n_fields, X.data_ptr(), st))
         else:
             W = t32(rs.uniform(low=-_bound(col, row), high=_bound(col, row), size=(row, col)))
             bh = torch.zeros(col, dtype=torch.float32, device=dev)
