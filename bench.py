@@ -183,7 +183,7 @@ def main():
             for i in range(min(args.steps, 100)):
                 step(i)
         torch.cuda.synchronize(dev)
-        for name in ('step1', 'step2', 'step3', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
+        for name in ('step1', 'step2', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
                      'scatter', 'finalize'):
             kern_ms[name] = eng.prof_get(name)[0]
         eng.prof_enable(False)

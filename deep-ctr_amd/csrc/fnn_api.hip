@@ -45,6 +45,7 @@ struct fnn_handle {
     bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
     float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
     bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
+    int role_off = 0;           // diagnostics only (FNN_ROLE_OFF): 1 sort, 2 dense, 4 sparse roles of launches 2/3 skipped
     // FM table
     float* table16 = nullptr; int32_t* field_of_row = nullptr; int64_t n_rows = 0; float w0 = 0.f;
     // dense
@@ -208,10 +209,15 @@ template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T
         else hipLaunchKernelGGL((k_step1<T, 1, 1, 4, false>), g, b, lds, h->st, a);
     }
 }
-void launch_sort16(fnn_handle* h, const SortArgs& so) {
-    if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(so.nblk), dim3(256),
-                                     sort_lds_bytes<unsigned long long>(), h->st, so);
-    else hipLaunchKernelGGL((k_sort16<unsigned>), dim3(so.nblk), dim3(256), sort_lds_bytes<unsigned>(), h->st, so);
+void launch_sort16(fnn_handle* h, const SortArgs& so) {      // split sort: 256-key runs, then the rank merge
+    const int F = so.nblk;
+    if (h->key64) {
+        hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, h->st, so);
+        hipLaunchKernelGGL((k_sortB<unsigned long long>), dim3(16 * F), dim3(256), SORT_N * 8, h->st, so);
+    } else {
+        hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, h->st, so);
+        hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, h->st, so);
+    }
 }
 
 // Launches 2 and 3 of a step.  `dense`: weight gradients / slab reduce (+ update); `sparse`: the
@@ -222,7 +228,9 @@ template <typename T>
 void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
 {
     const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
-    const bool have_next = sparse && h->pend_have_next;
+    const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
+    if (h->role_off & 2) dense = false;                     // timing experiments: results are wrong by construction
+    if (h->role_off & 4) sparse = false;
     const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
     {
         ProfScope ps(h, dense && sparse ? "step2" : (dense ? "step2_dense" : "step2_sparse"), h->st);
@@ -234,10 +242,10 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
                     have_next ? 4 * h->F : 0, h->skeys};
         const dim3 grid(so.nblk + nwx * h->splitk + nsc);
         if (h->key64)
-            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 1024 * 8, h->st, so, wa, nwx,
+            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 0, h->st, so, wa, nwx,
                                h->splitk, sa);
         else
-            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 1024 * 4, h->st, so, wa, nwx, h->splitk, sa);
+            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 0, h->st, so, wa, nwx, h->splitk, sa);
     }
     {
         ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
@@ -246,7 +254,7 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
                     h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
                     h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? h->F : 0, h->skeys};
+                    have_next ? 16 * h->F : 0, h->skeys};
         const dim3 grid(so.nblk + nred + (sparse ? 256 : 0));    // 256 workgroups walk the multi-chunk segments
         const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
         if (h->key64) {
@@ -452,6 +460,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
     h->bf16 = cfg->precision == FNN_PREC_BF16;
     if (const char* ev = getenv("FNN_NO_FUSE")) h->fused = !(ev[0] == '1');
+    if (const char* ev = getenv("FNN_ROLE_OFF")) h->role_off = atoi(ev);
     const size_t ts = tsize(h), Ba = h->ldT;
     CK(alloc_dev(h, &h->master, h->nw));
     h->off_bag = h->nw12 + (size_t)h->H2p * 64;

@@ -4,8 +4,8 @@
 // stream, each a union of two independent roles that run side by side on different workgroups:
 //
 //   k_step1 = { MLP strip kernel: gather, forward, loss, backward-data }
-//   k_step2 = { weight-gradient products } U { sparse-row SGD, level 1 } U { sort quarters of the NEXT batch's keys }
-//   k_step3 = { slab reduce + dense SGD + shadow refresh } U { sparse-row SGD, level 2 } U { merge the quarters }
+//   k_step2 = { weight-gradient products } U { sparse-row SGD, level 1 } U { sort runs of the NEXT batch's keys }
+//   k_step3 = { slab reduce + dense SGD + shadow refresh } U { sparse-row SGD, level 2 } U { rank-merge the runs }
 //
 // The step is a few microseconds of math, so its cost is launches and dependent memory round
 // trips; three fat launches and no cross-stream events are what that regime wants (measured:
@@ -16,10 +16,11 @@
 namespace fnn {
 
 // ------------------------------------------------------------------------------------------
-// Grouping role: bitonic sort of one field's 4096 (row, t) keys by 256 threads x 16 keys.
-// Strides below 16 are compare-exchanges inside a thread, strides 16..512 use wave shuffles,
-// only strides 1024 and 2048 go through LDS.  32-bit keys (row << 12 | t) when n_rows * 4096
-// fits, else 64-bit.  Segment bounds [s, e) come from a max-scan / min-scan of the head flags.
+// Grouping role: a field's 4096 (row, t) keys sorted in two independent phases -- 16 runs of 256
+// keys, each bitonic-sorted inside ONE wave's registers (phase A), then a merge by rank in which
+// every key finds its final place and its segment [s, e) with binary searches over the runs
+// (phase B).  32-bit keys (row << 12 | t) when n_rows * 4096 fits, else 64-bit.  Measured against
+// the single-kernel bitonic network it replaced: 34 us -> 2 x ~4 us of role time.
 // ------------------------------------------------------------------------------------------
 template <typename KT> struct KeyTraits;
 template <> struct KeyTraits<unsigned> { static constexpr int SH = 12; };
@@ -29,203 +30,132 @@ struct SortArgs { const int32_t* ids; int B, F; int64_t n_rows; int4* rec; int* 
 
 constexpr int SORT_N = 4096;     // keys per field handled by the union-kernel path (B <= 4096)
 
-template <typename KT> __host__ __device__ constexpr size_t sort_lds_bytes() {
-    return (size_t)SORT_N * sizeof(KT) + 256 * sizeof(KT) + 2 * 256 * sizeof(int);
+template <typename KT> __host__ __device__ constexpr size_t sort_lds_bytes() { return (size_t)SORT_N * sizeof(KT); }
+
+// Invalid entries (t >= B, id outside the table) carry the all-ones row, so that every key of a
+// field is distinct (the rank merges below need a strict total order) and they sort to the end.
+template <typename KT> __device__ __forceinline__ KT inv_row() { return (~(KT)0) >> KeyTraits<KT>::SH; }
+
+// first index in the ascending run q[0 .. 1 << LOG) whose key is >= v (branch-free; q in LDS)
+template <typename KT, int LOG>
+__device__ __forceinline__ int lower_bound_pow2(const KT* q, const KT v) {
+    int base = 0;
+#pragma unroll
+    for (int s = 1 << (LOG - 1); s >= 1; s >>= 1) base += (q[base + s - 1] < v) ? s : 0;
+    return base + ((q[base] < v) ? 1 : 0);
 }
 
-// Phase A of the split sort: one workgroup sorts a quarter (1024 keys, 256 threads x 4) of a
-// field's keys, ascending or descending as the full network would at k = 1024, and stores it.
+// Phase A of the split sort: every wave bitonic-sorts a run of 256 keys in registers (4 per lane:
+// strides below 4 inside the lane, the rest wave shuffles -- no LDS, no barriers) and stores it.
+// One workgroup = 4 runs = a quarter of a field; so.nblk = 4 F.
 template <typename KT>
-__device__ __forceinline__ void sortA_body(const SortArgs& so, const int blk, unsigned char* smem)
+__device__ __forceinline__ void sortA_body(const SortArgs& so, const int blk, unsigned char*)
 {
     constexpr int SH = KeyTraits<KT>::SH;
-    const KT INV = ~(KT)0;
-    KT* s_key = reinterpret_cast<KT*>(smem);                 // [1024]
-    const int tid = threadIdx.x, F = so.F, B = so.B;
-    const int f = blk >> 2, base = (blk & 3) * 1024;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, F = so.F, B = so.B;
+    const int f = blk >> 2, base = (blk & 3) * 1024 + wave * 256;
     KT key[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {                             // coalesced over tid; initial order is free
-        const int t = base + a * 256 + tid;
-        KT kk = INV;
+    for (int a = 0; a < 4; ++a) {                             // initial order inside a run is free
+        const int t = base + a * 64 + lane;
+        KT row = inv_row<KT>();
         if (t < B) {
             const int64_t id = so.ids[(size_t)t * F + f];
-            if (id >= 0 && id < so.n_rows) kk = ((KT)id << SH) | (KT)t;
+            if (id >= 0 && id < so.n_rows) row = (KT)id;
         }
-        key[a] = kk;
+        key[a] = (row << SH) | (KT)t;
     }
-    const int i0 = base + tid * 4;                            // global position of key[0]
-    for (int k = 2; k <= 1024; k <<= 1) {
+    const int i0 = lane * 4;                                  // position of key[0] in the run
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j < 4) {
 #pragma unroll
-                for (int jj = 2; jj > 0; jj >>= 1) {
-                    if (j == jj) {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const int b = a ^ jj;
-                            if (b > a) {
-                                const bool up = ((i0 + a) & k) == 0;
-                                const KT x = key[a], y = key[b];
-                                const KT mn = x < y ? x : y, mx = x < y ? y : x;
-                                key[a] = up ? mn : mx; key[b] = up ? mx : mn;
-                            }
-                        }
+                for (int a = 0; a < 4; ++a) {
+                    const int b = a ^ j;
+                    if (b > a) {
+                        const bool up = ((i0 + a) & k) == 0;
+                        const KT x = key[a], y = key[b];
+                        const KT mn = x < y ? x : y, mx = x < y ? y : x;
+                        key[a] = up ? mn : mx; key[b] = up ? mx : mn;
                     }
                 }
             } else {
                 const bool keepmin = ((i0 & j) == 0) == ((i0 & k) == 0);
-                if (j < 256) {
-                    const int d = j >> 2;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const KT other = __shfl_xor(key[a], d);
-                        const KT mine = key[a];
-                        const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
-                        key[a] = keepmin ? mn : mx;
-                    }
-                } else {
-                    __syncthreads();
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) s_key[tid * 4 + a] = key[a];
-                    __syncthreads();
-                    const int pt = (tid ^ (j >> 2)) * 4;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const KT other = s_key[pt + a];
-                        const KT mine = key[a];
-                        const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
-                        key[a] = keepmin ? mn : mx;
-                    }
+                for (int a = 0; a < 4; ++a) {
+                    const KT other = __shfl_xor(key[a], j >> 2);
+                    const KT mine = key[a];
+                    const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                    key[a] = keepmin ? mn : mx;
                 }
             }
         }
     }
-    KT* out = static_cast<KT*>(so.skeys) + (size_t)f * SORT_N + i0;
+    KT* out = static_cast<KT*>(so.skeys) + (size_t)f * SORT_N + base + i0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) out[a] = key[a];
 }
 
-// The whole sort (MERGE = false) or phase B of the split sort (MERGE = true: the keys come from
-// phase A's four sorted quarters and only the merge levels k = 2048, 4096 remain), then the
-// segment bounds.
-template <typename KT, bool MERGE>
-__device__ __forceinline__ void sort16_body(const SortArgs& so, const int f, unsigned char* smem)
+// Phase B of the split sort: merge by RANK.  A key's place in the field's final order is its index
+// in its own run plus, for each of the 15 other runs, the number of keys below it (a 9-step binary
+// search in LDS); its segment [s, e) comes the same way: s = keys below (row, 0), e = keys below
+// (row + 1, 0).  Every key is independent -- one thread per key, 16 workgroups per field
+// (so.nblk = 16 F), one barrier -- instead of a 15 us chain of dependent merge stages.
+template <typename KT>
+__device__ __forceinline__ void sortB_body(const SortArgs& so, const int blk, unsigned char* smem)
 {
     constexpr int SH = KeyTraits<KT>::SH;
-    const KT INV = ~(KT)0;
-    KT* s_key = reinterpret_cast<KT*>(smem);                 // [4096]
-    KT* s_last = s_key + SORT_N;                              // [256]
-    int* s_a = reinterpret_cast<int*>(s_last + 256);          // [256]
-    int* s_b = s_a + 256;                                     // [256]
-    const int tid = threadIdx.x, F = so.F, B = so.B;
-    if (f == 0 && tid == 0) *so.owner_cnt = 0;
-    KT key[16];
-    if (MERGE) {
-        const KT* in = static_cast<const KT*>(so.skeys) + (size_t)f * SORT_N + tid * 16;
+    KT* s_key = reinterpret_cast<KT*>(smem);                 // [4096] the 16 sorted runs
+    const int tid = threadIdx.x, f = blk >> 4, run = blk & 15;
+    if (blk == 0 && tid == 0) *so.owner_cnt = 0;
+    const KT* in = static_cast<const KT*>(so.skeys) + (size_t)f * SORT_N;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) key[a] = in[a];
-    } else {
+    for (int a = 0; a < 16; ++a) s_key[a * 256 + tid] = in[a * 256 + tid];
+    __syncthreads();
+    const KT key = s_key[run * 256 + tid];
+    const KT row = key >> SH, lo_key = row << SH, hi_key = (row + 1) << SH;    // row + 1 wraps only for invalid entries
+    // 48 binary searches (16 runs x {key, lo_key, hi_key}) advance in lockstep, so that every step
+    // issues 48 independent LDS reads instead of one dependent read at a time.  The search of the
+    // key in its own run returns its own index, so no run is special.
+    int bp[16], bs[16], be[16];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {                        // coalesced over tid; initial order is free
-            const int t = a * 256 + tid;
-            KT kk = INV;
-            if (t < B) {
-                const int64_t id = so.ids[(size_t)t * F + f];
-                if (id >= 0 && id < so.n_rows) kk = ((KT)id << SH) | (KT)t;
-            }
-            key[a] = kk;
+    for (int r = 0; r < 16; ++r) bp[r] = bs[r] = be[r] = r * 256;
+#pragma unroll
+    for (int st = 128; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const KT vp = s_key[bp[r] + st - 1], vs = s_key[bs[r] + st - 1], ve = s_key[be[r] + st - 1];
+            bp[r] += vp < key ? st : 0; bs[r] += vs < lo_key ? st : 0; be[r] += ve < hi_key ? st : 0;
         }
     }
-    for (int k = MERGE ? 2048 : 2; k <= SORT_N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < 16) {
+    int pos = 0, s = 0, e = 0;
 #pragma unroll
-                for (int jj = 8; jj > 0; jj >>= 1) {
-                    if (j == jj) {
-#pragma unroll
-                        for (int a = 0; a < 16; ++a) {
-                            const int b = a ^ jj;
-                            if (b > a) {
-                                const bool up = ((tid * 16 + a) & k) == 0;
-                                const KT x = key[a], y = key[b];
-                                const KT mn = x < y ? x : y, mx = x < y ? y : x;
-                                key[a] = up ? mn : mx; key[b] = up ? mx : mn;
-                            }
-                        }
-                    }
-                }
-            } else if (j < 1024) {
-                const int d = j >> 4;
-                const bool keepmin = (((tid << 4) & j) == 0) == (((tid << 4) & k) == 0);
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    const KT other = __shfl_xor(key[a], d);
-                    const KT mine = key[a];
-                    const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
-                    key[a] = keepmin ? mn : mx;
-                }
-            } else {
-                const bool keepmin = (((tid << 4) & j) == 0) == (((tid << 4) & k) == 0);
-                __syncthreads();
-#pragma unroll
-                for (int a = 0; a < 16; ++a) s_key[tid * 16 + a] = key[a];
-                __syncthreads();
-                const int pt = (tid ^ (j >> 4)) * 16;
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    const KT other = s_key[pt + a];
-                    const KT mine = key[a];
-                    const KT mn = mine < other ? mine : other, mx = mine < other ? other : mine;
-                    key[a] = keepmin ? mn : mx;
-                }
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        pos += bp[r] - r * 256 + (s_key[bp[r]] < key ? 1 : 0);
+        s += bs[r] - r * 256 + (s_key[bs[r]] < lo_key ? 1 : 0);
+        e += be[r] - r * 256 + (s_key[be[r]] < hi_key ? 1 : 0);
     }
-    // ---- segment bounds: s = position of the last head at or before p, e = next head after p
-    s_last[tid] = key[15];
-    __syncthreads();
-    const KT prev = tid > 0 ? s_last[tid - 1] : INV;
-    const int p0 = tid * 16;
-    unsigned headmask = 0;
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        const KT pk = a == 0 ? prev : key[a - 1];
-        const bool head = (a == 0 && tid == 0) || ((pk >> SH) != (key[a] >> SH));
-        headmask |= head ? (1u << a) : 0u;
-    }
-    const int last_head = headmask ? p0 + 31 - __builtin_clz(headmask) : -1;
-    const int first_head = headmask ? p0 + __builtin_ctz(headmask) : SORT_N;
-    // exclusive prefix-max of last_head and exclusive suffix-min of first_head over the 256 threads
-    s_a[tid] = last_head; s_b[tid] = first_head;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int va = (tid >= o) ? s_a[tid - o] : -1;
-        const int vb = (tid + o < 256) ? s_b[tid + o] : SORT_N;
-        __syncthreads();
-        s_a[tid] = max(s_a[tid], va); s_b[tid] = min(s_b[tid], vb);
-        __syncthreads();
-    }
-    const int carry_s = tid > 0 ? s_a[tid - 1] : -1;
-    const int carry_e = tid < 255 ? s_b[tid + 1] : SORT_N;
-    int4* out = so.rec + (size_t)f * SORT_N + p0;
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        const unsigned below = headmask & ((2u << a) - 1u);           // heads at positions <= a
-        const unsigned above = a == 15 ? 0u : (headmask >> (a + 1));  // heads at positions > a
-        const int s = below ? p0 + 31 - __builtin_clz(below) : carry_s;
-        const int e = above ? p0 + a + 1 + __builtin_ctz(above) : carry_e;
-        int4 r = make_int4(-1, 0, 0, 0);
-        if (key[a] != INV) r = make_int4((int)(key[a] >> SH), (int)(key[a] & (((KT)1 << SH) - 1)), s, e);
-        out[a] = r;
-    }
+    int4 rr = make_int4(-1, 0, 0, 0);
+    if (row != inv_row<KT>()) rr = make_int4((int)row, (int)(key & (((KT)1 << SH) - 1)), s, e);
+    so.rec[(size_t)f * SORT_N + pos] = rr;
 }
 
+// The split sort as two plain launches, for a batch nobody announced (fnn_prefetch_ids) and for
+// the inner-product family: 4 F then 16 F workgroups, ~7 us each instead of the 34 us single-kernel
+// bitonic network.
 template <typename KT>
-static __global__ __launch_bounds__(256) void k_sort16(const SortArgs so)
+static __global__ __launch_bounds__(256) void k_sortA(const SortArgs so)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    sort16_body<KT, false>(so, blockIdx.x, smem);
+    sortA_body<KT>(so, blockIdx.x, smem);
+}
+template <typename KT>
+static __global__ __launch_bounds__(256) void k_sortB(const SortArgs so)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    sortB_body<KT>(so, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -240,7 +170,7 @@ static __global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------
-// step 2: quarter-sorts of the NEXT batch's keys  U  weight gradients  U  sparse-row SGD level 1
+// step 2: run-sorts of the NEXT batch's keys  U  weight gradients  U  sparse-row SGD level 1
 // ------------------------------------------------------------------------------------------
 template <typename T, typename KT>
 static __global__ __launch_bounds__(256) void k_step2(const SortArgs so, const WgradArgs wa, const int nwx,
@@ -271,7 +201,7 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_sum[16][16];
-    if ((int)blockIdx.x < so.nblk) { sort16_body<KT, true>(so, blockIdx.x, smem); return; }   // merge: F or 0 WGs
+    if ((int)blockIdx.x < so.nblk) { sortB_body<KT>(so, blockIdx.x, smem); return; }          // rank merge: 16 F or 0 WGs
     const int b = (int)blockIdx.x - so.nblk;
     if (b >= ta.nblk_red) {
         const int nb = (int)gridDim.x - so.nblk - ta.nblk_red;

@@ -2,7 +2,7 @@
 // (include/ipnn_hip.h).  Replaces the TensorFlow graph of python/FNN_IP_L7.py:102-133 (forward),
 // :82-88 (loss) and its gradient step (plain SGD).  Built from the FNN path's pieces: fragment-tiled
 // MFMA GEMMs with fused epilogues (k_gemm), the split-K weight-gradient kernel (k_wgrad) and the
-// sorted, atomics-free sparse-row update (k_sort16 / k_scat1 / k_scat2) -- plus two kernels of its
+// sorted, atomics-free sparse-row update (k_sortA / k_sortB / k_scat1 / k_scat2) -- plus two kernels of its
 // own for the inner-product layer.
 #include <hip/hip_runtime.h>
 
@@ -282,8 +282,13 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     if (train) {
         IpProf ps(h, "sort");
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
-        if (h->key64) hipLaunchKernelGGL((k_sort16<unsigned long long>), dim3(F), dim3(256), sort_lds_bytes<unsigned long long>(), h->st, so);
-        else hipLaunchKernelGGL((k_sort16<unsigned>), dim3(F), dim3(256), sort_lds_bytes<unsigned>(), h->st, so);
+        if (h->key64) {
+            hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, h->st, so);
+            hipLaunchKernelGGL((k_sortB<unsigned long long>), dim3(16 * F), dim3(256), SORT_N * 8, h->st, so);
+        } else {
+            hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, h->st, so);
+            hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, h->st, so);
+        }
     }
     {
         IpProf ps(h, "ip_fwd");
