@@ -209,9 +209,10 @@ def main():
                              'unit': 'GB/s'}}
 
     # ---- CPU baseline: the C port of the oracle on this host, 1 core, bounded sample
-    cpu = None
+    cpu = cpu_vec = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not snn:
         cpu = cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
+        cpu_vec = cpu_baseline_vectorised(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
 
     if rank == 0:
         out = {
@@ -227,7 +228,7 @@ def main():
                        'parallelism': 'dp%d' % world if world > 1 else 'single'},
             'train_logloss_last_step': last_loss,
             'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
-            'roofline': roofline, 'cpu_baseline': cpu, 'kernel_ms': kern_ms,
+            'roofline': roofline, 'cpu_baseline': cpu, 'cpu_baseline_vectorised': cpu_vec, 'kernel_ms': kern_ms,
         }
         print(json.dumps(out))
     if dist is not None:
@@ -371,6 +372,33 @@ def cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, seconds):
     return {'value': n * B / el, 'unit': 'examples/sec', 'cores': 1, 'kind': 'port',
             'sample': '%d steps of batch %d on the same table/ids (oracle/fnn_oracle.c, float64, scalar; host has '
                       '%d cores)' % (n, B, os.cpu_count())}
+
+
+def cpu_baseline_vectorised(rows, ids_np, y_np, m1_np, m2_np, p0, B, seconds):
+    """SURVEY 8d variant (ii): the oracle's batch-level NumPy step (fancy-index gather, BLAS GEMMs,
+    argsort-grouped closed-form row update) in float64 on all the host's cores -- what a fair CPU
+    implementation costs; the scalar C port above stands for the reference's per-element loops."""
+    from oracle import fnn_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([t.get('num_threads', 1) for t in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rows64 = np.array(rows, dtype=np.float64)
+    p = {k: (np.array(v, dtype=np.float64) if not np.isscalar(v) else float(v)) for k, v in p0.items()}
+    n, t0 = 0, time.perf_counter()
+    while True:
+        b = n % (len(y_np) // B)
+        sl = slice(b * B, (b + 1) * B)
+        orc.train_step_vec(p, rows64, -3.0, ids_np[sl], y_np[sl].astype(np.float64), m1_np[b].astype(np.float64),
+                           m2_np[b].astype(np.float64), 0.001, 0.0, 0.1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 2000:
+            break
+    return {'value': n * B / el, 'unit': 'examples/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d steps of batch %d on the same table/ids (oracle.fnn_oracle.train_step_vec: NumPy float64, BLAS on %d '
+                      'threads; host has %d cores)' % (n, B, threads, os.cpu_count())}
 
 
 if __name__ == '__main__':

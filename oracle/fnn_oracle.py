@@ -376,3 +376,52 @@ def snn_train_step(p, ww0, bb0, ids, y, r1, r2, lr, lambda1, acti_type='tanh'):
 def snn_predict(p, ww0, bb0, ids, acti_type='tanh'):
     """python/SNN_RBM.py:162-198 auc_rmse's forward: bag -> predict."""
     return predict(p, snn_bag(ww0, bb0, ids), acti_type)
+
+
+# --------------------------------------------------------------------------- vectorised CPU variant
+def gather_vec(rows, ids, w_0):
+    """A3 with one fancy-index gather per batch (CPU baseline variant ii)."""
+    B, F = ids.shape
+    K = rows.shape[1]
+    x = np.empty((B, 1 + F * K))
+    x[:, 0] = w_0
+    g = rows[np.where(ids >= 0, ids, 0)]                       # [B, F, K]
+    g[ids < 0] = 0.0
+    x[:, 1:] = g.reshape(B, F * K)
+    return x
+
+
+def scatter_sgd_vec(rows, ids, gx, lr, lambda_fm, b_size=None):
+    """A6 in closed form, vectorised: per field a stable argsort groups the (row, t) pairs, a row
+    hit by m examples ends at row*c^m - lr*sum_j g_j*c^(m-j) (the reference's sequential loop,
+    python/FNN_wnzh.py:299-306; checked against scatter_sgd).  In place on rows."""
+    B, F = ids.shape
+    K = rows.shape[1]
+    c = 1 - 2. * lambda_fm * lr / (b_size if b_size is not None else B)
+    for f in range(F):
+        col = ids[:, f]
+        live = np.nonzero(col >= 0)[0]
+        if len(live) == 0:
+            continue
+        order = live[np.argsort(col[live], kind='stable')]
+        r = col[order]
+        head = np.r_[True, r[1:] != r[:-1]]
+        start = np.nonzero(head)[0]
+        seg = np.cumsum(head) - 1
+        m = np.diff(np.r_[start, len(r)])
+        pos = np.arange(len(r)) - start[seg]                    # j - 1 inside the segment
+        w = c ** (m[seg] - 1 - pos)
+        g = gx[order, 1 + f * K:1 + (f + 1) * K] * w[:, None]
+        acc = np.add.reduceat(g, start, axis=0)
+        ur = r[start]
+        rows[ur] = rows[ur] * (c ** m)[:, None] - lr * acc
+    return rows
+
+
+def train_step_vec(p, rows, w_0, ids, y, r1, r2, lr, lambda1, lambda_fm, acti_type='tanh', b_size=None):
+    """The hot loop body with batch-level NumPy/BLAS calls on all cores: what a fair CPU
+    implementation of the reference's step costs (the reference itself walks Python loops)."""
+    x = gather_vec(rows, ids, w_0)
+    gx, pre, loss, p_drop, g = train_call(p, x, y, r1, r2, lr, lambda1, acti_type)
+    scatter_sgd_vec(rows, ids, gx, lr, lambda_fm, b_size)
+    return {'gx': gx, 'loss': loss, 'p_drop': p_drop}

@@ -305,3 +305,29 @@ def test_dae_oracle_gradients_and_quirks(tmp_path):
     np.testing.assert_allclose(h, do.sigmoid(np.cumsum(bag) + b_pre))                         # Q3
     Wl, bl, st2 = do.da(6, 4, lines, res, epochs=1)
     assert not np.array_equal(Wl, st2['W'])                                                   # Q2 again
+
+
+def test_vectorised_cpu_variant_equals_the_sequential_oracle():
+    """oracle.train_step_vec (the multi-core CPU baseline of bench.py) against the line-by-line
+    restatement: same gather, same dense step, same rows after the decayed sparse update, with
+    duplicates, an empty field and a global batch length."""
+    rng = np.random.RandomState(3)
+    F, K, H1, H2, B = 16, 4, 9, 5, 60
+    sizes = [5] * F
+    rows = rng.standard_normal((sum(sizes), K)) * 0.2
+    off = np.cumsum([0] + sizes[:-1])
+    ids = (off + rng.randint(0, 5, (B, F))).astype(np.int32)
+    ids[7, 3] = -1
+    y = (rng.uniform(size=B) < 0.4).astype(np.float64)
+    p = {'w1': rng.standard_normal((1 + F * K, H1)) * 0.3, 'b1': np.zeros(H1), 'w2': rng.standard_normal((H1, H2)) * 0.3,
+         'b2': np.zeros(H2), 'w3': rng.standard_normal(H2) * 0.3, 'b3': 0.1}
+    r1 = (rng.uniform(size=H1) < 0.5).astype(np.float64); r2 = (rng.uniform(size=H2) < 0.5).astype(np.float64)
+    pa = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ra, rb = rows.copy(), rows.copy()
+    a = orc.train_step(pa, ra, -1.5, ids, y, r1, r2, 0.05, 0.01, 0.2, b_size=80)
+    b = orc.train_step_vec(p, rb, -1.5, ids, y, r1, r2, 0.05, 0.01, 0.2, b_size=80)
+    np.testing.assert_allclose(orc.gather_vec(rows, ids, -1.5), orc.gather(rows, ids, -1.5), rtol=0, atol=0)
+    np.testing.assert_allclose(b['gx'], a['gx'], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(rb, ra, rtol=1e-12, atol=1e-14)
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+        np.testing.assert_allclose(p[k], pa[k], rtol=1e-13, atol=1e-15)
