@@ -111,6 +111,21 @@ DAE_SIGNATURES = {
     "dae_bag_cumsum_sigmoid": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
 }
 
+# every symbol include/fm_hip.h declares
+FM_SIGNATURES = {
+    "fm_last_error": (C.c_char_p, [_vp]),
+    "fm_create": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "fm_destroy": (_i, [_vp]),
+    "fm_sync": (_i, [_vp]),
+    "fm_set_table": (_i, [_vp, _vp, _i64]),
+    "fm_get_table": (_i, [_vp, _vp]),
+    "fm_get_rows": (_i, [_vp, _vp, _i64, _vp]),
+    "fm_set_b": (_i, [_vp, _f]),
+    "fm_get_b": (_i, [_vp, C.POINTER(_f)]),
+    "fm_train_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, C.POINTER(_f)]),
+    "fm_predict": (_i, [_vp, _vp, _i, _vp]),
+}
+
 _i64p = C.POINTER(_i64)
 # every symbol include/ctr_ingest.h declares (host code: native text ingestion)
 CTR_SIGNATURES = {
@@ -148,7 +163,7 @@ def load():
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in list(SIGNATURES.items()) + list(RBM_SIGNATURES.items()) + list(IPNN_SIGNATURES.items()) + \
-            list(CTR_SIGNATURES.items()) + list(DAE_SIGNATURES.items()):
+            list(CTR_SIGNATURES.items()) + list(DAE_SIGNATURES.items()) + list(FM_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

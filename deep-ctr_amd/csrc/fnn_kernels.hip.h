@@ -1031,10 +1031,13 @@ __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
     if (G >= F * NQ) return;
     const int f = G / NQ, q = G % NQ, base = q * 16;
     const int4 mine = rec[(size_t)f * N2 + base + l];
+    // both decay factors of an entry depend on its record only: its own weight c^(e-1-pos) and its
+    // segment's c^(e-s) -- fetched together with the gradients and the old rows, not after them
     const double wmine = (mine.x >= 0) ? cpow[mine.w - 1 - (base + l)] : 0.0;
+    const double cmine = (mine.x >= 0) ? cpow[mine.w - mine.z] : 0.0;
     int row[16], sg[16], eg[16];
     float g[16], wold[16];
-    double w[16];
+    double w[16], cs[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         row[j] = __shfl(mine.x, j, 16);
@@ -1042,6 +1045,7 @@ __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
         sg[j] = __shfl(mine.z, j, 16);
         eg[j] = __shfl(mine.w, j, 16);
         w[j] = __shfl(wmine, j, 16);
+        cs[j] = __shfl(cmine, j, 16);
         const bool live = row[j] >= 0 && l < K;
         g[j] = live ? gxp[(size_t)t * K1p + f * SLOT + l] : 0.f;
         wold[j] = live ? table16[(size_t)row[j] * SLOT + l] : 0.f;
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
         if (!last) continue;
         const int s = sg[j], e = eg[j];
         if (s >= base && e <= base + 16) {                 // the whole segment lies in this chunk
-            if (l < K) table16[(size_t)row[j] * SLOT + l] = (float)((double)wold[j] * cpow[e - s] - lr * acc);
+            if (l < K) table16[(size_t)row[j] * SLOT + l] = (float)((double)wold[j] * cs[j] - lr * acc);
         } else {
             const int which = (s < base) ? 0 : 1;          // 0: enters from the left; 1: opens here
             part[(((size_t)f * NQ + q) * 2 + which) * SLOT + l] = acc;

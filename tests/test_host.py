@@ -34,6 +34,11 @@ def test_header_symbols_are_exported_and_bound(built):
     for name in declared:
         assert hasattr(lib, name), name
     hdr = open(os.path.join(ROOT, 'include', 'ipnn_hip.h')).read()
+    hdr_f = open(os.path.join(ROOT, 'include', 'fm_hip.h')).read()
+    declared_f = set(re.findall(r'\b(fm_[a-z0-9_]+)\s*\(', hdr_f))
+    assert declared_f == set(_capi.FM_SIGNATURES), declared_f ^ set(_capi.FM_SIGNATURES)
+    for name in declared_f:
+        assert hasattr(lib, name), name
     hdr_d = open(os.path.join(ROOT, 'include', 'dae_hip.h')).read()
     declared_d = set(re.findall(r'\b(dae_[a-z0-9_]+)\s*\(', hdr_d))
     assert declared_d == set(_capi.DAE_SIGNATURES), declared_d ^ set(_capi.DAE_SIGNATURES)

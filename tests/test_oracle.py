@@ -331,3 +331,24 @@ def test_vectorised_cpu_variant_equals_the_sequential_oracle():
     np.testing.assert_allclose(rb, ra, rtol=1e-12, atol=1e-14)
     for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
         np.testing.assert_allclose(p[k], pa[k], rtol=1e-13, atol=1e-15)
+
+
+def test_fm_oracle_gradient_is_the_dense_sgd_of_the_loss():
+    """oracle/fm_oracle.py: one sgd_step equals theta - lr * numerical gradient of loss_value (data term
+    + lambda * l2_loss over ALL parameters), with a repeated row and an absent field."""
+    from oracle import fm_oracle as fo
+    rng = np.random.RandomState(2)
+    rows = rng.standard_normal((12, 4)) * 0.3
+    ids = rng.randint(0, 12, (5, 3)).astype(np.int32); ids[1, 2] = -1; ids[2] = ids[0]
+    y = (rng.uniform(size=5) < 0.5).astype(np.float64)
+    for reduce_mean in (True, False):
+        r = rows.copy()
+        b_new, data, p = fo.sgd_step(r, 0.2, ids, y, 0.1, 0.05, reduce_mean)
+        eps = 1e-6
+        for (i, j) in ((int(ids[0, 0]), 0), (int(ids[0, 1]), 2), (11, 3)):
+            rp, rm = rows.copy(), rows.copy(); rp[i, j] += eps; rm[i, j] -= eps
+            g = (fo.loss_value(rp, 0.2, ids, y, 0.05, reduce_mean)[0] - fo.loss_value(rm, 0.2, ids, y, 0.05, reduce_mean)[0]) / (2 * eps)
+            assert abs(r[i, j] - (rows[i, j] - 0.1 * g)) < 1e-8
+        gb = (fo.loss_value(rows, 0.2 + eps, ids, y, 0.05, reduce_mean)[0] - fo.loss_value(rows, 0.2 - eps, ids, y, 0.05, reduce_mean)[0]) / (2 * eps)
+        assert abs(b_new - (0.2 - 0.1 * gb)) < 1e-8
+        assert abs(data - fo.loss_value(rows, 0.2, ids, y, 0.05, reduce_mean)[1]) < 1e-12
