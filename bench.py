@@ -328,15 +328,17 @@ def bench_ipnn(args):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of this same command; profiles/r01g_pmc_traffic.json, KB).
-    gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced
-    reads, so it is doubled (an upper bound for the mixed access widths of these kernels)."""
-    path = os.path.join(ROOT, 'profiles', 'r01g_pmc_traffic.json')
-    if not os.path.exists(path):
+    WRITE_SIZE collected in separate runs of this same command, tools/pmc_traffic.sh; the newest
+    profiles/*_pmc_traffic.json, KB).  gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports
+    half the bytes of wide coalesced reads, so it is doubled (an upper bound for the mixed access
+    widths of these kernels)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
         return None
     tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
-    for name, v in json.load(open(path)).items():
-        if tag and tag in name:
+    for name, v in json.load(open(files[-1])).items():
+        if tag and tag in name and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
             return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
     return None
 

@@ -255,6 +255,7 @@ template <typename T> struct EpiBwd {        // A5: delta = (delta_next * W^T) *
     }
 };
 struct EpiF32 {                               // plain float output (gx', split-K slabs)
+    static constexpr bool TILE = false;
     float* out; int ld; size_t zstride;
     __device__ void operator()(int row0, int col, const f32x4& acc, int z) const {
         float* o = out + (size_t)z * zstride;
@@ -291,6 +292,107 @@ static __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, in
 #pragma unroll
     for (int n = 0; n < NT; ++n) epi(r0, (ct0 + n) * 16 + (lane & 15), acc[n], 0);
 }
+
+// ------------------------------------------------------------------------------------------
+// MFMA GEMM on two FRAGMENT-TILED operands:  C[M][N] = sum_k A[M][k] * B[N][k], both stored with
+// ft_off (16 rows x KS k-values = one contiguous 1-KiB fragment in lane order), so every operand
+// load of a wave is one coalesced 16 B/lane read straight into MFMA registers: no LDS, no
+// barriers.  A wave owns a (16 TM) x (16 TN) block of C (64 x 64 at TM = TN = 4: 16 MFMAs per
+// 8 fragment loads), a workgroup 2 x 2 waves; the next k-step's fragments are in flight while the
+// current one multiplies.  grid = (ceil(M / 32 TM), ceil(N / 32 TN), splitK); rows / columns are
+// multiples of 16 TM / 16 TN.  The deep stack of the inner-product family runs all three of its
+// products per layer on it (forward, backward-data, weight gradient).
+// ------------------------------------------------------------------------------------------
+template <typename T, int TM, int TN, typename Epi>
+static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A, const T* __restrict__ Bm, int mt16, int nt16,
+                                                  int nkt_all, int nkt, Epi epi)
+{
+    typedef typename Traits<T>::frag frag;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rt0 = (blockIdx.x * 2 + (wave & 1)) * TM, ct0 = (blockIdx.y * 2 + (wave >> 1)) * TN;
+    if (rt0 >= mt16 || ct0 >= nt16) return;
+    const int kt0 = blockIdx.z * nkt;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // three register stages: the fragments of k-steps kt + 1 and kt + 2 are in flight while kt multiplies
+    // (one L2 round trip is ~2-3 k-steps of MFMA time at two waves per SIMD)
+    frag a0[TM], b0[TN], a1[TM], b1[TN], a2[TM], b2[TN];
+    auto load = [&](frag* a, frag* b, int kt) {
+        if (kt >= nkt) return;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const frag*>(ft_frag<T>(A, rt0 + m, kt0 + kt, nkt_all, lane));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const frag*>(ft_frag<T>(Bm, ct0 + n, kt0 + kt, nkt_all, lane));
+    };
+    auto mul = [&](const frag* a, const frag* b) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) mma(acc[m][n], a[m], b[n]);
+    };
+    load(a0, b0, 0);
+    load(a1, b1, 1);
+    for (int kt = 0; kt < nkt; kt += 3) {
+        load(a2, b2, kt + 2);
+        mul(a0, b0);
+        if (kt + 1 >= nkt) break;
+        load(a0, b0, kt + 3);
+        mul(a1, b1);
+        if (kt + 2 >= nkt) break;
+        load(a1, b1, kt + 4);
+        mul(a2, b2);
+    }
+    const int rq = 4 * (lane >> 4), cl = lane & 15;              // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    if constexpr (Epi::TILE) {
+        // Activation-like output in both fragment-tiled orientations.  xT (rows = columns of C,
+        // k = rows of C): the lane's 4 accumulator rows are 4 consecutive k -> one 8-byte store.
+        // xF (rows = rows of C, k = columns): 16 rows at a time go through a wave-private LDS tile and
+        // leave as whole 1-KiB fragments (16 B per lane, fully coalesced) instead of 2-byte stores.
+        typedef typename Traits<T>::frag frag_t;
+        constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, LDP = 16 * TN + 8, KT = 16 * TN / KS;
+        extern __shared__ __align__(16) unsigned char gemm_smem[];
+        T* tile = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * 16 * LDP;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                float v[4];
+                const int r0 = (rt0 + m) * 16 + rq, col = (ct0 + n) * 16 + cl;
+                epi.pre(r0, col, acc[m][n], v);
+                if (epi.outT) store4(epi.outT + ft_off<T>(col, r0, epi.ldT), v[0], v[1], v[2], v[3]);
+                if (epi.outF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile[(rq + r) * LDP + n * 16 + cl] = (T)v[r];
+                }
+            }
+            if (epi.outF) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) {
+                    const frag_t f = *reinterpret_cast<const frag_t*>(tile + (lane & 15) * LDP + kk * KS + (lane >> 4) * EPL);
+                    T* dst = epi.outF + ((size_t)((rt0 + m) * (epi.ld / KS) + (ct0 * 16) / KS + kk) * 64 + lane) * EPL;
+                    *reinterpret_cast<frag_t*>(dst) = f;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) epi((rt0 + m) * 16 + rq, (ct0 + n) * 16 + cl, acc[m][n], (int)blockIdx.z);
+    }
+}
+
+// dynamic LDS of k_gemm_ft for a tile epilogue: 4 wave-private [16][16 TN + 8] tiles
+template <typename T, int TN> constexpr size_t gemm_ft_lds() { return (size_t)4 * 16 * (16 * TN + 8) * sizeof(T); }
 
 // Weight gradients: gw = P^T Q with the contraction over the examples t (python/FNN_wnzh.py:174),
 // for the three products of a step in ONE launch: x'^T delta1, d1^T delta2, d2^T delta3.  Both

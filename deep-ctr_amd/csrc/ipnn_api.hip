@@ -1,7 +1,8 @@
 // ipnn_api.hip -- the inner-product FNN family (FNN_IP_L3 / L5 / L7) on gfx950: kernels + C ABI
 // (include/ipnn_hip.h).  Replaces the TensorFlow graph of python/FNN_IP_L7.py:102-133 (forward),
-// :82-88 (loss) and its gradient step (plain SGD).  Built from the FNN path's pieces: fragment-tiled
-// MFMA GEMMs with fused epilogues (k_gemm), the split-K weight-gradient kernel (k_wgrad) and the
+// :82-88 (loss) and its gradient step (plain SGD).  Built from the FNN path's pieces: the
+// fragment-tiled MFMA GEMM with fused epilogues (k_gemm_ft: forward, backward-data and the split-K
+// weight-gradient product of every layer, 64 x 64 per wave, operands double-buffered in registers) and the
 // sorted, atomics-free sparse-row update (k_sortA / k_sortB / k_scat1 / k_scat2) -- plus two kernels of its
 // own for the inner-product layer.
 #include <hip/hip_runtime.h>
@@ -42,6 +43,8 @@ __device__ inline float ip_dact_u(float u, int act) {
 // 16 examples per workgroup.  a0' [Ba][D0p] in "slot" layout: column 16 f + l = e_f[l],
 // columns 16F .. 16F+P-1 the P = F(F-1)/2 pair products (row-major i < j), column CB = b,
 // column CB+1 = 1 (carries h1_b); every real column goes through act and the keep-mask / keep.
+// a0 is written fragment-tiled twice: a0F (rows = examples, k = columns: the next forward product's
+// A operand) and a0T (rows = columns, k = examples: the weight-gradient product's A operand).
 // ------------------------------------------------------------------------------------------
 struct IpFwdArgs {
     const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; const float* b;
@@ -88,7 +91,7 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
         sa[e] = v;
     }
     __syncthreads();
-    for (int e = tid; e < 16 * a.D0p; e += 256) a0[(size_t)(t0 + e / a.D0p) * a.D0p + e % a.D0p] = (T)sa[e];
+    for (int e = tid; e < 16 * a.D0p; e += 256) a0[ft_off<T>(t0 + e / a.D0p, e % a.D0p, a.D0p)] = (T)sa[e];
     for (int e = tid; e < a.D0p * 4; e += 256) {
         const int c = e >> 2, tq = e & 3;
         store4(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
@@ -140,31 +143,37 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
 // ------------------------------------------------------------------------------------------
 // GEMM epilogues of the deep stack.
 // ------------------------------------------------------------------------------------------
+// All activation / delta matrices of the stack are FRAGMENT-TILED (ft_off) in both orientations:
+// xF (rows = examples, k = units) feeds the next forward / backward-data product, xT (rows = units,
+// k = examples) the weight-gradient product.  Only dz1 (f32, for the inner-product backward) is row-major.
+// The epilogues compute the 4 values a lane owns (rows r0 .. r0+3 of one column); k_gemm_ft writes both
+// layouts.  Keep-masks are read TRANSPOSED ([unit][example], k_mask_T below): a lane's 4 rows are 4
+// consecutive bytes, one dword load; activations for act' come from xT the same way (one 8-byte load).
 template <typename T> struct EpiIpFwd {      // a_t = mask/keep * act(l_t); ones column at d
-    T* out; int ld; T* outT; int ldT; const uint8_t* mask; float inv_keep; int act, d, B;
-    __device__ void operator()(int row0, int col, const f32x4& acc, int) const {
-        float v[4];
+    static constexpr bool TILE = true;
+    T* outF; int ld; T* outT; int ldT; const uint8_t* maskT; float inv_keep; int act, d, B;
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
+        unsigned mb = 0x01010101u;
+        if (maskT && col < d) mb = *reinterpret_cast<const unsigned*>(maskT + (size_t)col * ldT + r0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = row0 + r;
+            const int t = r0 + r;
             float x = 0.f;
             if (t < B) {
-                if (col < d) x = ip_act(acc[r], act) * (mask ? (float)mask[(size_t)t * d + col] * inv_keep : 1.0f);
+                if (col < d) x = ip_act(acc[r], act) * ((float)((mb >> (8 * r)) & 0xffu) * (maskT ? inv_keep : 1.0f));
                 else if (col == d) x = 1.0f;
             }
             v[r] = x;
-            out[(size_t)t * ld + col] = (T)x;
         }
-        store4(outT + ft_off<T>(col, row0, ldT), v[0], v[1], v[2], v[3]);
     }
 };
 template <typename T> struct EpiIpOut {      // logits (column 0), loss, delta = sigmoid(logit) - y
-    T* dl; int ld; T* dlT; int ldT; const float* y; float* logits; float* loss_t; float* p_out; int B;
-    __device__ void operator()(int row0, int col, const f32x4& acc, int) const {
-        float v[4];
+    static constexpr bool TILE = true;
+    T* outF; int ld; T* outT; int ldT; const float* y; float* logits; float* loss_t; float* p_out; int B;
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = row0 + r;
+            const int t = r0 + r;
             float x = 0.f;
             if (col == 0 && t < B) {
                 const float z = acc[r], p = 1.0f / (1.0f + expf(-z));
@@ -173,33 +182,61 @@ template <typename T> struct EpiIpOut {      // logits (column 0), loss, delta =
                 if (y) { x = p - y[t]; loss_t[t] = fmaxf(z, 0.f) - z * y[t] + log1pf(expf(-fabsf(z))); }
             } else if (col == 0 && loss_t) loss_t[t] = 0.f;
             v[r] = x;
-            if (dl) dl[(size_t)t * ld + col] = (T)x;
         }
-        if (dlT) store4(dlT + ft_off<T>(col, row0, ldT), v[0], v[1], v[2], v[3]);
     }
 };
 template <typename T> struct EpiIpBwd {      // delta l_t = (delta l_{t+1} W^T) * mask/keep * act'(l_t)
-    T* out; int ld; T* outT; int ldT; float* out32; const T* a; const uint8_t* mask; float inv_keep, keep; int act, d, B;
-    // layer 0 (out32 != null): `mask` is indexed through `ref` (slot column -> reference column)
-    const int* ref; int dref;
-    __device__ void operator()(int row0, int col, const f32x4& acc, int) const {
-        float v[4];
+    static constexpr bool TILE = true;
+    T* outF; int ld; T* outT; int ldT; float* out32; int ld32; const T* aT; const uint8_t* maskT; float inv_keep, keep; int act, d, B;
+    const int* ref;          // layer 0 (out32 != null): slot column -> reference column, -1 = padding
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
+        const bool real = ref ? ref[col] >= 0 : col < d;
+        unsigned mb = 0x01010101u;
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (real) {
+            if (maskT) mb = *reinterpret_cast<const unsigned*>(maskT + (size_t)col * ldT + r0);
+            u = load4(aT + ft_off<T>(col, r0, ldT));
+        }
+        const float uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = row0 + r;
+            const int t = r0 + r;
             float x = 0.f;
-            const int mc = ref ? ref[col] : (col < d ? col : -1);
-            if (t < B && mc >= 0) {
-                const float m = mask ? (float)mask[(size_t)t * (ref ? dref : d) + mc] : 1.0f;
-                const float u = (float)a[(size_t)t * ld + col] * (mask ? keep : 1.0f);      // act(l_t) where m = 1
-                x = acc[r] * m * (mask ? inv_keep : 1.0f) * ip_dact_u(u, act);
+            if (t < B && real) {
+                const float m = (float)((mb >> (8 * r)) & 0xffu);
+                x = acc[r] * m * (maskT ? inv_keep : 1.0f) * ip_dact_u(uu[r] * (maskT ? keep : 1.0f), act);   // act(l_t) where m = 1
             }
             v[r] = x;
-            if (out32) out32[(size_t)t * ld + col] = x; else out[(size_t)t * ld + col] = (T)x;
+            if (out32) out32[(size_t)t * ld32 + col] = x;
         }
-        if (outT) store4(outT + ft_off<T>(col, row0, ldT), v[0], v[1], v[2], v[3]);
     }
 };
+
+// Keep-masks [B][d] uint8 (the ABI's layout, reference column order) -> [Dp][ldT] uint8, zero padded,
+// for every layer in one launch; layer 0's columns are mapped to the slot layout on the way.
+struct MaskTArgs {
+    const uint8_t* src[IPNN_MAX_HIDDEN + 1]; uint8_t* dst[IPNN_MAX_HIDDEN + 1]; int d[IPNN_MAX_HIDDEN + 1], Dp[IPNN_MAX_HIDDEN + 1];
+    int tile0[IPNN_MAX_HIDDEN + 2]; int n; const int* ref0; int B, Ba, ldT;
+};
+static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
+{
+    __shared__ uint8_t s[64][80];
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < a.n && (int)blockIdx.x >= a.tile0[q]) ? 1 : 0;
+    const int local = (int)blockIdx.x - a.tile0[t], ntx = a.Ba / 64;
+    const int t0 = (local % ntx) * 64, c0 = (local / ntx) * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int tt = i >> 6, cc = i & 63, ex = t0 + tt, c = c0 + cc;
+        int sc = c < a.Dp[t] ? c : -1;
+        if (t == 0) sc = sc >= 0 ? a.ref0[sc] : -1; else if (sc >= a.d[t]) sc = -1;
+        s[cc][tt] = (ex < a.B && sc >= 0) ? a.src[t][(size_t)ex * a.d[t] + sc] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int cc = threadIdx.x >> 2, q = threadIdx.x & 3;
+    if (c0 + cc < a.Dp[t])
+        *reinterpret_cast<uint4*>(a.dst[t] + (size_t)(c0 + cc) * a.ldT + t0 + 16 * q) = *reinterpret_cast<const uint4*>(&s[cc][16 * q]);
+}
 
 // W_t <- W_t - lr * sum of slabs; refresh both tiled shadows.  Layer 1 rows are in slot layout.
 template <typename T>
@@ -218,26 +255,57 @@ static __global__ void k_ip_update(float* __restrict__ W, const float* __restric
     wf[ft_off<T>(c, r, Din)] = (T)w;
     wb[ft_off<T>(r, c, Dout)] = (T)w;
 }
-static __global__ void k_ip_update_b(float* b, const float* gb_part, int n, float lr, const float* loss_t, int Ba, float* loss_sum)
+// One launch for the whole stack: W_t <- W_t - lr * (sum of its split-K slabs), both tiled shadows
+// refreshed; the last workgroup applies the bias-of-z1 gradient and reduces the per-example losses.
+struct IpUpdArgs {
+    float* W[IPNN_MAX_HIDDEN + 1]; void* wf[IPNN_MAX_HIDDEN + 1]; void* wb[IPNN_MAX_HIDDEN + 1];
+    size_t off[IPNN_MAX_HIDDEN + 2];                 // element offset of every layer in a slab; off[n] = total
+    int Din[IPNN_MAX_HIDDEN + 1], Dout[IPNN_MAX_HIDDEN + 1], sk[IPNN_MAX_HIDDEN + 1]; int n;
+    const float* slab; size_t zstride; float lr;
+    float* b; const float* gb_part; int ngb; const float* loss_t; int Ba; float* loss_sum;
+};
+template <typename T>
+static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
 {
-    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s += gb_part[i]; if (lr != 0.f) *b -= lr * s; }
-    __shared__ float sl[256];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < Ba; i += 256) v += loss_t[i];
-    sl[threadIdx.x] = v; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) *loss_sum = sl[0];
+    if (blockIdx.x == gridDim.x - 1) {               // scalar tail: b and the loss, fixed-shape trees
+        __shared__ float sl[256], sg[256];
+        float v = 0.f, g = 0.f;
+        for (int i = threadIdx.x; i < u.Ba; i += 256) v += u.loss_t[i];
+        for (int i = threadIdx.x; i < u.ngb; i += 256) g += u.gb_part[i];
+        sl[threadIdx.x] = v; sg[threadIdx.x] = g; __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sg[threadIdx.x] += sg[threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { *u.loss_sum = sl[0]; *u.b -= u.lr * sg[0]; }
+        return;
+    }
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= u.off[u.n]) return;
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < u.n && i >= u.off[q]) ? 1 : 0;
+    const size_t j = i - u.off[t];
+    float g = 0.f;
+    for (int z = 0; z < u.sk[t]; ++z) g += u.slab[(size_t)z * u.zstride + i];
+    const float w = u.W[t][j] - u.lr * g;
+    u.W[t][j] = w;
+    const int r = (int)(j / u.Dout[t]), c = (int)(j % u.Dout[t]);
+    static_cast<T*>(u.wf[t])[ft_off<T>(c, r, u.Din[t])] = (T)w;
+    static_cast<T*>(u.wb[t])[ft_off<T>(r, c, u.Dout[t])] = (T)w;
 }
 
 }  // namespace
 
 struct ipnn_handle {
     ipnn_cfg cfg{}; std::string err; int dev = 0; hipStream_t st = nullptr; bool own_stream = false;
-    int F = 0, K = 0, L = 0, P = 0, CB = 0, Bmax = 0, ldT = 0; bool bf16 = false; int splitk = 8;
+    int F = 0, K = 0, L = 0, P = 0, CB = 0, Bmax = 0, ldT = 0; bool bf16 = false; int splitk = 8;   // splitk: slab capacity
+    std::vector<int> sk;                         // split-K of each layer's weight-gradient product
     std::vector<int> d, Dp;                      // d[0..L+1], padded
     float* table16 = nullptr; int64_t n_rows = 0; float* b = nullptr;
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
+    std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
     float *dz0 = nullptr, *gxp = nullptr, *gb_part = nullptr, *loss_t = nullptr, *loss_dev = nullptr, *slab = nullptr;
     int* ref0 = nullptr; int* err_flag = nullptr;
     int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr; void* skeys = nullptr;
@@ -268,7 +336,7 @@ size_t ts(const ipnn_handle* h) { return h->bf16 ? 2 : 4; }
 template <typename T> void ip_refresh(ipnn_handle* h, int t, const float* slab, float lr) {      // t = 1..L+1
     const int Din = h->Dp[t - 1], Dout = h->Dp[t];
     const size_t n = (size_t)Din * Dout;
-    hipLaunchKernelGGL((k_ip_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->W[t - 1], slab, h->splitk,
+    hipLaunchKernelGGL((k_ip_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->W[t - 1], slab, h->sk[t - 1],
                        h->slab_stride, lr, Din, Dout, (T*)h->wf[t - 1], (T*)h->wb[t - 1]);
 }
 
@@ -296,19 +364,46 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag};
         hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0]);
     }
+    // one product: C [M][N] = A . B^T on fragment-tiled operands; narrow problems take smaller wave tiles
+    auto gemm = [&](const T* A, const T* Bm, int M, int N, int nkt_all, int nkt, int splitk, auto epi) {
+        typedef decltype(epi) E;
+        const int mt16 = M / 16, nt16 = N / 16;
+        const long wg44 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+        const size_t lds4 = E::TILE ? gemm_ft_lds<T, 4>() : 0, lds2 = E::TILE ? gemm_ft_lds<T, 2>() : 0;
+        if (wg44 >= 160)
+            hipLaunchKernelGGL((k_gemm_ft<T, 4, 4, E>), dim3((M + 127) / 128, (N + 127) / 128, splitk), dim3(256), lds4, h->st, A, Bm,
+                               mt16, nt16, nkt_all, nkt, epi);
+        else if (N > 64)
+            hipLaunchKernelGGL((k_gemm_ft<T, 2, 4, E>), dim3((M + 63) / 64, (N + 127) / 128, splitk), dim3(256), lds4, h->st, A, Bm,
+                               mt16, nt16, nkt_all, nkt, epi);
+        else
+            hipLaunchKernelGGL((k_gemm_ft<T, 2, 2, E>), dim3((M + 63) / 64, (N + 63) / 64, splitk), dim3(256), lds2, h->st, A, Bm,
+                               mt16, nt16, nkt_all, nkt, epi);
+    };
+    const bool drop = train && masks;
+    if (drop) {   // keep-masks of all layers -> transposed, padded, slot-ordered for layer 0
+        MaskTArgs ma{};
+        int tiles = 0;
+        for (int t = 0; t <= L; ++t) {
+            if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
+            ma.src[t] = masks[t]; ma.dst[t] = h->maskT[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
+            tiles += (Ba / 64) * (h->Dp[t] / 64);
+        }
+        ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
+        hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->st, ma);
+    }
+    constexpr int KS = Traits<T>::KS;
     {
     IpProf ps(h, "fwd");
     for (int t = 1; t <= L; ++t) {       // l_t = a_{t-1} W_t ; a_t = drop(act(l_t))
-        EpiIpFwd<T> e{(T*)h->a[t], h->Dp[t], (T*)h->aT[t], ldT, (train && masks) ? masks[t] : nullptr,
-                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->d[t], B};
-        hipLaunchKernelGGL((k_gemm<T, 4, EpiIpFwd<T>>), dim3(Ba / 64, h->Dp[t] / 64, 1), dim3(256), 0, h->st, (const T*)h->a[t - 1],
-                           h->Dp[t - 1], (const T*)h->wf[t - 1], h->Dp[t - 1], e);
+        EpiIpFwd<T> e{(T*)h->a[t], h->Dp[t], (T*)h->aT[t], ldT, drop ? h->maskT[t] : nullptr, drop ? inv_keep : 1.0f, h->cfg.act,
+                      h->d[t], B};
+        gemm((const T*)h->a[t - 1], (const T*)h->wf[t - 1], Ba, h->Dp[t], h->Dp[t - 1] / KS, h->Dp[t - 1] / KS, 1, e);
     }
     {
         EpiIpOut<T> e{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                       logits_out, h->loss_t, p_out, B};
-        hipLaunchKernelGGL((k_gemm<T, 4, EpiIpOut<T>>), dim3(Ba / 64, h->Dp[L + 1] / 64, 1), dim3(256), 0, h->st, (const T*)h->a[L],
-                           h->Dp[L], (const T*)h->wf[L], h->Dp[L], e);
+        gemm((const T*)h->a[L], (const T*)h->wf[L], Ba, h->Dp[L + 1], h->Dp[L] / KS, h->Dp[L] / KS, 1, e);
     }
     }
     if (!train) { IHK(h, hipGetLastError()); return FNN_OK; }
@@ -317,21 +412,19 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     for (int t = L + 1; t >= 1; --t) {   // delta l_{t-1} from delta l_t ; then gW_t = a_{t-1}^T delta l_t
         const bool first = (t == 1);
         EpiIpBwd<T> e{first ? nullptr : (T*)h->dl[t - 2], h->Dp[t - 1], first ? nullptr : (T*)h->dlT[t - 2], ldT,
-                      first ? h->dz0 : nullptr, (const T*)h->a[t - 1], masks ? masks[t - 1] : nullptr, inv_keep, keep,
-                      h->cfg.act, h->d[t - 1], B, first ? h->ref0 : nullptr, h->d[0]};
-        hipLaunchKernelGGL((k_gemm<T, 4, EpiIpBwd<T>>), dim3(Ba / 64, h->Dp[t - 1] / 64, 1), dim3(256), 0, h->st, (const T*)h->dl[t - 1],
-                           h->Dp[t], (const T*)h->wb[t - 1], h->Dp[t], e);
+                      first ? h->dz0 : nullptr, h->Dp[0], (const T*)h->aT[t - 1], drop ? h->maskT[t - 1] : nullptr, inv_keep, keep,
+                      h->cfg.act, h->d[t - 1], B, first ? h->ref0 : nullptr};
+        gemm((const T*)h->dl[t - 1], (const T*)h->wb[t - 1], Ba, h->Dp[t - 1], h->Dp[t] / KS, h->Dp[t] / KS, 1, e);
     }
     }
-    {   // all weight gradients: one problem per layer, own slab region each
+    {   // all weight gradients: gW_t [Dp_{t-1}][Dp_t] = a_{t-1}^T . delta l_t, contraction over the examples,
+        // split-K slabs (the split chosen per layer so that every product fills the chip)
         IpProf ps(h, "wgrad");
         size_t off = 0;
         for (int t = 1; t <= L + 1; ++t) {
-            WgradArgs wa;
-            wa.p[0] = WgradProb{h->aT[t - 1], h->dlT[t - 1], h->slab + off, h->Dp[t - 1] / 64, h->Dp[t] / 64, h->Dp[t]};
-            wa.p[1] = wa.p[2] = wa.p[3] = WgradProb{nullptr, nullptr, nullptr, 0, 1, 64};
-            wa.ldT = ldT; wa.klen = Ba / h->splitk; wa.zstride = h->slab_stride;
-            hipLaunchKernelGGL((k_wgrad<T>), dim3((h->Dp[t - 1] / 64) * (h->Dp[t] / 64), h->splitk), dim3(256), 0, h->st, wa);
+            const int sk = h->sk[t - 1];
+            EpiF32 e{h->slab + off, h->Dp[t], h->slab_stride};
+            gemm((const T*)h->aT[t - 1], (const T*)h->dlT[t - 1], h->Dp[t - 1], h->Dp[t], ldT / KS, Ba / KS / sk, sk, e);
             off += (size_t)h->Dp[t - 1] * h->Dp[t];
         }
     }
@@ -350,8 +443,15 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {
         IpProf ps(h, "update");
         size_t off = 0;
-        for (int t = 1; t <= L + 1; ++t) { ip_refresh<T>(h, t, h->slab + off, h->cfg.lr); off += (size_t)h->Dp[t - 1] * h->Dp[t]; }
-        hipLaunchKernelGGL(k_ip_update_b, dim3(1), dim3(256), 0, h->st, h->b, h->gb_part, Ba / 16, h->cfg.lr, h->loss_t, Ba, h->loss_dev);
+        IpUpdArgs u{};
+        for (int t = 1; t <= L + 1; ++t) {
+            u.W[t - 1] = h->W[t - 1]; u.wf[t - 1] = h->wf[t - 1]; u.wb[t - 1] = h->wb[t - 1]; u.off[t - 1] = off;
+            u.Din[t - 1] = h->Dp[t - 1]; u.Dout[t - 1] = h->Dp[t]; u.sk[t - 1] = h->sk[t - 1];
+            off += (size_t)h->Dp[t - 1] * h->Dp[t];
+        }
+        u.n = L + 1; u.off[L + 1] = off; u.slab = h->slab; u.zstride = h->slab_stride; u.lr = h->cfg.lr;
+        u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
+        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off + 255) / 256 + 1)), dim3(256), 0, h->st, u);
     }
     IHK(h, hipGetLastError());
     return FNN_OK;
@@ -385,6 +485,13 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
     for (int t = 1; t <= h->L; ++t) { h->d[t] = cfg->hidden[t - 1]; h->Dp[t] = rup(h->d[t] + 1, 64); if (h->d[t] < 1 || h->d[t] > 4095) { h->err = "hidden size out of range"; return fail(FNN_ERR_ARG); } }
     h->d[h->L + 1] = 1; h->Dp[h->L + 1] = 64;
+    h->sk.resize(h->L + 1);
+    for (int t = 1; t <= h->L + 1; ++t) {                          // ~256 workgroups of 128 x 128 per product
+        const int tiles = ((h->Dp[t - 1] + 127) / 128) * ((h->Dp[t] + 127) / 128);
+        int sk = 1;
+        while (sk < h->splitk && tiles * sk * 2 <= 288) sk *= 2;
+        h->sk[t - 1] = sk;
+    }
     auto al = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, h->st); return e; };
     const size_t Ba = h->ldT, tsz = ts(h);
     size_t nw = 0;
@@ -396,6 +503,8 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(al(&h->dl[t - 1], Ba * h->Dp[t] * tsz)); IK(al(&h->dlT[t - 1], Ba * h->Dp[t] * tsz));
     }
     for (int t = 0; t <= h->L; ++t) { IK(al(&h->a[t], Ba * h->Dp[t] * tsz)); IK(al(&h->aT[t], Ba * h->Dp[t] * tsz)); }
+    h->maskT.assign(h->L + 1, nullptr);
+    for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT[t], Ba * h->Dp[t]));
     h->slab_stride = nw;
     IK(al((void**)&h->slab, (size_t)h->splitk * nw * 4));
     IK(al((void**)&h->dz0, Ba * h->Dp[0] * 4)); IK(al((void**)&h->gxp, Ba * h->Dp[0] * 4));
@@ -428,6 +537,7 @@ int ipnn_destroy(ipnn_handle* h)
     if (h->st) hipStreamSynchronize(h->st);
     for (auto v : {&h->wf, &h->wb, &h->a, &h->aT, &h->dl, &h->dlT}) for (void* p : *v) if (p) hipFree(p);
     for (float* p : h->W) if (p) hipFree(p);
+    for (uint8_t* p : h->maskT) if (p) hipFree(p);
     void* ptrs[] = {h->table16, h->b, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
                     h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1};
     for (void* p : ptrs) if (p) hipFree(p);
