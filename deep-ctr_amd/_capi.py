@@ -109,6 +109,10 @@ DAE_SIGNATURES = {
     "dae_sparse_epoch": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, C.POINTER(C.c_double), _vp]),
     "dae_dense_epoch": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, C.POINTER(C.c_double), _vp]),
     "dae_bag_cumsum_sigmoid": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
+    "dae_sparse_epoch_f64": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, C.c_double, C.POINTER(C.c_double), _vp]),
+    "dae_dense_epoch_f64": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_double, _i, C.POINTER(C.c_double), _vp]),
+    "dae_bag_cumsum_sigmoid_f64": (_i, [_vp, _vp, _i, _i64, _vp, _i, _i, _vp, _vp]),
+    "dae_affine_sigmoid_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 # every symbol include/fm_hip.h declares

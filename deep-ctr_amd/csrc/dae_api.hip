@@ -23,6 +23,7 @@ thread_local std::string g_err;
 #define DFAIL(code, msg) do { g_err = (msg); return (code); } while (0)
 
 __device__ inline float sigm(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ inline double sigm(double z) { return 1.0 / (1.0 + exp(-z)); }
 __device__ inline float wave_sum(float v) {
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
     v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
@@ -31,28 +32,39 @@ __device__ inline float wave_sum(float v) {
 // -x log z - (1-x) log(1-z), the terms with a zero factor dropped as Theano's 0 * log(.) = 0 would
 // only differ at z in {0, 1}
 __device__ inline float xent(float x, float z) { return -(x * logf(z) + (1.0f - x) * logf(1.0f - z)); }
+__device__ inline double xent(double x, double z) { return -(x * log(z) + (1.0 - x) * log(1.0 - z)); }
+__device__ inline double wave_sum(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
 
-struct SparseArgs {
-    const float* table; int64_t n_rows; float *bhid, *bvis, *bhid_prev; const int32_t* idx; const float* x;
-    int64_t N; int H, S; float lr; double* cost; int* err;
+// S = float (the fast mode) or double (the reference's own precision: its float64 trajectory is
+// sensitive enough at lr = 0.1 that only an f64 run tracks it over thousands of steps).
+template <typename S> struct SparseArgs {
+    const S* table; int64_t n_rows; S *bhid, *bvis, *bhid_prev; const int32_t* idx; const S* x;
+    int64_t N; int H, S_; S lr; double* cost; int* err;
 };
 
-__global__ __launch_bounds__(256) void k_dae_sparse(const SparseArgs a)
+template <typename S>
+__global__ __launch_bounds__(256) void k_dae_sparse(const SparseArgs<S> a)
 {
-    __shared__ float s_w[32][257];
-    __shared__ float s_y[256], s_d[32], s_x[32], s_c[32];
-    const int tid = threadIdx.x, H = a.H, S = a.S;
+    extern __shared__ __align__(16) unsigned char dae_smem[];
+    S (*s_w)[257] = reinterpret_cast<S (*)[257]>(dae_smem);                 // [32][257]
+    S* s_y = reinterpret_cast<S*>(dae_smem) + 32 * 257;                      // [256]
+    S* s_d = s_y + 256; S* s_x = s_d + 32; S* s_c = s_x + 32;               // [32] each
+    const int tid = threadIdx.x, H = a.H, Sn = a.S_;
     const bool act = tid < H;
-    float bh = act ? a.bhid[tid] : 0.f, bh_prev = bh;
-    float bv = (tid < S) ? a.bvis[tid] : 0.f;                    // thread j < S also owns positional visible bias j
+    S bh = act ? a.bhid[tid] : (S)0, bh_prev = bh;
+    S bv = (tid < Sn) ? a.bvis[tid] : (S)0;                      // thread j < S also owns positional visible bias j
     double cost = 0.0;
-    float wn[32];                                                 // rows of the NEXT example
+    S wn[32];                                                     // rows of the NEXT example
     auto fetch = [&](int64_t n) {
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-            float v = 0.f;
-            if (act && j < S && n < a.N) {
-                const int64_t id = a.idx[n * S + j];
+            S v = (S)0;
+            if (act && j < Sn && n < a.N) {
+                const int64_t id = a.idx[n * Sn + j];
                 if (id >= 0 && id < a.n_rows) v = a.table[(size_t)id * H + tid]; else if (tid == 0) atomicOr(a.err, 1);
             }
             wn[j] = v;
@@ -60,50 +72,136 @@ __global__ __launch_bounds__(256) void k_dae_sparse(const SparseArgs a)
     };
     fetch(0);
     for (int64_t n = 0; n < a.N; ++n) {
-        float wc[32];
+        S wc[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) wc[j] = wn[j];
-        if (tid < 32) s_x[tid] = tid < S ? a.x[n * S + tid] : 0.f;
+        if (tid < 32) s_x[tid] = tid < Sn ? a.x[n * Sn + tid] : (S)0;
         fetch(n + 1);                                             // in flight under this example's arithmetic
         __syncthreads();
-        float z = bh;                                             // y = sigmoid(x W + b)            (:94)
+        S z = bh;                                                 // y = sigmoid(x W + b)            (:94)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) z = fmaf(s_x[j], wc[j], z);
-        const float y = act ? sigm(z) : 0.f;
+        for (int j = 0; j < 32; ++j) z = fma(s_x[j], wc[j], z);
+        const S y = act ? sigm(z) : (S)0;
         s_y[tid] = y;
 #pragma unroll
         for (int j = 0; j < 32; ++j) s_w[j][tid] = wc[j];
         __syncthreads();
         {   // z_j = sigmoid(y . W[j,:] + bvis_j)                                                    (:97)
             const int j = tid >> 3, seg = tid & 7;
-            float acc = 0.f;
-            for (int i = seg; i < H; i += 8) acc = fmaf(s_y[i], s_w[j][i], acc);
+            S acc = (S)0;
+            for (int i = seg; i < H; i += 8) acc = fma(s_y[i], s_w[j][i], acc);
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
             if (seg == 0) s_c[j] = acc;
         }
         __syncthreads();
         if (tid < 32) {
-            float d = 0.f;
-            if (tid < S) {
-                const float zj = sigm(s_c[tid] + bv), xj = s_x[tid];
+            S d = (S)0;
+            if (tid < Sn) {
+                const S zj = sigm(s_c[tid] + bv), xj = s_x[tid];
                 d = zj - xj;
                 s_c[tid] = xent(xj, zj);
                 bv -= a.lr * d;                                   // b' <- b' - lr (z - x)
-            } else s_c[tid] = 0.f;
+            } else s_c[tid] = (S)0;
             s_d[tid] = d;
         }
         __syncthreads();
-        float dy = 0.f;                                           // (d W) * y (1 - y)
+        S dy = (S)0;                                              // (d W) * y (1 - y)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) dy = fmaf(s_d[j], wc[j], dy);
-        dy *= y * (1.0f - y);
+        for (int j = 0; j < 32; ++j) dy = fma(s_d[j], wc[j], dy);
+        dy *= y * ((S)1 - y);
         bh_prev = bh;
         bh -= a.lr * dy;
-        if (tid == 0) { float c = 0.f; for (int j = 0; j < 32; ++j) c += s_c[j]; cost += (double)c; }
+        if (tid == 0) { double c = 0.0; for (int j = 0; j < 32; ++j) c += (double)s_c[j]; cost += c; }
     }
     if (act) { a.bhid[tid] = bh; a.bhid_prev[tid] = bh_prev; }
-    if (tid < S) a.bvis[tid] = bv;
+    if (tid < Sn) a.bvis[tid] = bv;
     if (tid == 0 && a.cost) *a.cost = cost;
+}
+template <typename S> constexpr size_t dae_sparse_lds() { return (size_t)(32 * 257 + 256 + 96) * sizeof(S); }
+
+// The dense trainer with W in global memory (L2-resident, one workgroup): any [row][col] up to
+// 1024 columns, float or double.  Four passes over W per example -- y = x W, z = W y, dy = d W, the
+// update -- with the next example's x W accumulated inside the update pass, so three reads and one
+// write of W per step.  The register-tiled k_dae_dense below is the fast f32 form of the same step.
+template <typename S> struct DenseGArgs { S *W, *bhid, *bvis; const S* X; int64_t N; int row, col; S lr; int skip_last; double* cost; };
+
+template <typename S>
+__global__ __launch_bounds__(1024) void k_dae_dense_g(const DenseGArgs<S> a)
+{
+    extern __shared__ __align__(16) unsigned char dae_smem[];
+    const int tid = threadIdx.x, row = a.row, col = a.col, w = tid >> 6, l = tid & 63;
+    const int CP = (col + 63) / 64 * 64, G = 1024 / CP, g = tid / CP, j = tid % CP;
+    const bool cact = g < G && j < col;
+    S* s_part = reinterpret_cast<S*>(dae_smem);                  // [G][CP] <= 1024
+    S* s_y = s_part + 1024; S* s_dy = s_y + CP;                  // [CP] each
+    S* s_x = s_dy + CP; S* s_xn = s_x + row; S* s_d = s_xn + row; S* s_bv = s_d + row;    // [row] each
+    double* s_cost = reinterpret_cast<double*>(s_bv + row + (row & 1));     // [16]
+    S bh = (tid < col) ? a.bhid[tid] : (S)0;
+    for (int i = tid; i < row; i += 1024) { s_x[i] = a.X[i]; s_bv[i] = a.bvis[i]; }
+    double cost = 0.0;
+    __syncthreads();
+    {   // x W of the first example
+        S p = (S)0;
+        if (cact) for (int i = g; i < row; i += G) p = fma(s_x[i], a.W[(size_t)i * col + j], p);
+        if (g < G) s_part[g * CP + j] = p;
+    }
+    __syncthreads();
+    for (int64_t n = 0; n < a.N; ++n) {
+        for (int i = tid; i < row; i += 1024) s_xn[i] = (n + 1 < a.N) ? a.X[(size_t)(n + 1) * row + i] : (S)0;
+        S y = (S)0;
+        if (tid < col) {
+            S s = bh;
+            for (int q = 0; q < G; ++q) s += s_part[q * CP + tid];
+            y = sigm(s);
+        }
+        if (tid < CP) s_y[tid] = y;
+        __syncthreads();
+        for (int i = w; i < row; i += 16) {                       // z_i = sigmoid(W[i,:] . y + b'_i), one wave per row
+            S acc = (S)0;
+            for (int c = l; c < col; c += 64) acc = fma(s_y[c], a.W[(size_t)i * col + c], acc);
+            acc = wave_sum(acc);
+            const S zi = sigm(acc + s_bv[i]), xi = s_x[i];
+            if (l == 0) s_d[i] = zi - xi;
+            cost += (double)xent(xi, zi);
+        }
+        __syncthreads();
+        {   // d W
+            S p = (S)0;
+            if (cact) for (int i = g; i < row; i += G) p = fma(s_d[i], a.W[(size_t)i * col + j], p);
+            if (g < G) s_part[g * CP + j] = p;
+        }
+        __syncthreads();
+        const S lr = (a.skip_last && n + 1 == a.N) ? (S)0 : a.lr;
+        if (tid < col) {
+            S s = (S)0;
+            for (int q = 0; q < G; ++q) s += s_part[q * CP + tid];
+            const S dy = s * y * ((S)1 - y);
+            s_dy[tid] = dy;
+            bh -= lr * dy;
+        }
+        __syncthreads();
+        {   // W <- W - lr (x (x) dy + d (x) y); the next example's x W rides on the same pass
+            S p = (S)0;
+            if (cact) {
+                const S dyj = s_dy[j], yj = s_y[j];
+                for (int i = g; i < row; i += G) {
+                    const size_t o = (size_t)i * col + j;
+                    const S wv = a.W[o] - lr * fma(s_x[i], dyj, s_d[i] * yj);
+                    a.W[o] = wv;
+                    p = fma(s_xn[i], wv, p);
+                }
+            }
+            if (g < G) s_part[g * CP + j] = p;
+        }
+        __syncthreads();
+        for (int i = tid; i < row; i += 1024) { s_bv[i] -= lr * s_d[i]; s_x[i] = s_xn[i]; }
+        __syncthreads();
+    }
+    for (int i = tid; i < row; i += 1024) a.bvis[i] = s_bv[i];
+    if (tid < col) a.bhid[tid] = bh;
+    if (l == 0) s_cost[w] = cost;
+    __syncthreads();
+    if (tid == 0 && a.cost) { double t = 0.0; for (int q = 0; q < 16; ++q) t += s_cost[q]; *a.cost = t; }
 }
 
 struct DenseArgs { float *W, *bhid, *bvis; const float* X; int64_t N; int row, col; float lr; int skip_last; double* cost; };
@@ -222,13 +320,14 @@ __global__ __launch_bounds__(1024) void k_dae_dense(const DenseArgs a)
     if (tid == 0 && a.cost) { double t = 0.0; for (int q = 0; q < 16; ++q) t += s_cost[q]; *a.cost = t; }
 }
 
-__global__ __launch_bounds__(1024) void k_dae_bag_cumsum(const float* __restrict__ W0, const float* __restrict__ b0, int H,
+template <typename S>
+__global__ __launch_bounds__(1024) void k_dae_bag_cumsum(const S* __restrict__ W0, const S* __restrict__ b0, int H,
                                                           int64_t n_rows, const int32_t* __restrict__ ids, int n, int F,
-                                                          float* __restrict__ out, int* __restrict__ err)
+                                                          S* __restrict__ out, int* __restrict__ err)
 {
-    __shared__ float s[2][1024];
+    __shared__ S s[2][1024];
     const int t = blockIdx.x, k = threadIdx.x;
-    float v = 0.f;
+    S v = (S)0;
     if (k < H) {
         for (int f = 0; f < F; ++f) {
             const int64_t id = ids[(size_t)t * F + f];
@@ -240,12 +339,24 @@ __global__ __launch_bounds__(1024) void k_dae_bag_cumsum(const float* __restrict
     s[0][k] = v;
     __syncthreads();
     for (int o = 1; o < (int)blockDim.x; o <<= 1) {               // inclusive scan over the hidden units (Q3)
-        const float add = k >= o ? s[cur][k - o] : 0.f;
+        const S add = k >= o ? s[cur][k - o] : (S)0;
         s[cur ^ 1][k] = s[cur][k] + add;
         cur ^= 1;
         __syncthreads();
     }
     if (k < H) out[(size_t)t * H + k] = sigm(s[cur][k] + b0[k]);
+}
+
+// out [n][b] = sigmoid(in [n][a] . W [a][b] + bias): the propagation between dense layers (:183-187), f64
+__global__ void k_dae_affine_sigmoid_f64(const double* __restrict__ in, const double* __restrict__ W, const double* __restrict__ bias,
+                                         int n, int a, int b, double* __restrict__ out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * b) return;
+    const int t = (int)(gid / b), c = (int)(gid % b);
+    double s = bias[c];
+    for (int i = 0; i < a; ++i) s = fma(in[(size_t)t * a + i], W[(size_t)i * b + c], s);
+    out[gid] = sigm(s);
 }
 
 int* g_flag(hipStream_t st) {
@@ -266,18 +377,24 @@ extern "C" {
 
 const char* dae_last_error(void) { return g_err.c_str(); }
 
-int dae_sparse_epoch(const float* table, int64_t n_rows, float* bhid, float* bvis, float* bhid_prev, const int32_t* idx,
-                     const float* x, int64_t N, int H, int S, float lr, double* cost_sum_out, void* stream)
+}  // extern "C" (templated bodies below)
+
+namespace {
+
+template <typename S>
+int sparse_epoch_t(const S* table, int64_t n_rows, S* bhid, S* bvis, S* bhid_prev, const int32_t* idx, const S* x, int64_t N, int H,
+                   int Sn, S lr, double* cost_sum_out, void* stream)
 {
     if (!table || !bhid || !bvis || !bhid_prev || !idx || !x) DFAIL(FNN_ERR_ARG, "null pointer");
-    if (N < 1 || H < 1 || H > 256 || S < 1 || S > 32 || n_rows < 1) DFAIL(FNN_ERR_ARG, "need N >= 1, 1 <= H <= 256, 1 <= S <= 32");
+    if (N < 1 || H < 1 || H > 256 || Sn < 1 || Sn > 32 || n_rows < 1) DFAIL(FNN_ERR_ARG, "need N >= 1, 1 <= H <= 256, 1 <= S <= 32");
     hipStream_t st = (hipStream_t)stream;
     int* flag = g_flag(st);
     if (!flag) DFAIL(FNN_ERR_HIP, "hipMalloc failed");
     double* dcost = nullptr;
     DHK(hipMalloc((void**)&dcost, 8));
-    SparseArgs a{table, n_rows, bhid, bvis, bhid_prev, idx, x, N, H, S, lr, dcost, flag};
-    hipLaunchKernelGGL(k_dae_sparse, dim3(1), dim3(256), 0, st, a);
+    SparseArgs<S> a{table, n_rows, bhid, bvis, bhid_prev, idx, x, N, H, Sn, lr, dcost, flag};
+    DHK(hipFuncSetAttribute((const void*)k_dae_sparse<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dae_sparse_lds<S>()));
+    hipLaunchKernelGGL((k_dae_sparse<S>), dim3(1), dim3(256), dae_sparse_lds<S>(), st, a);
     DHK(hipGetLastError());
     double c = 0.0;
     DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
@@ -289,21 +406,20 @@ int dae_sparse_epoch(const float* table, int64_t n_rows, float* bhid, float* bvi
     return FNN_OK;
 }
 
-int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t N, int row, int col, float lr,
-                    int skip_last_update, double* cost_sum_out, void* stream)
+template <typename S>
+int dense_g_epoch_t(S* W, S* bhid, S* bvis, const S* X, int64_t N, int row, int col, S lr, int skip_last, double* cost_sum_out,
+                    void* stream)
 {
     if (!W || !bhid || !bvis || !X) DFAIL(FNN_ERR_ARG, "null pointer");
-    if (N < 1 || row < 1 || col < 1) DFAIL(FNN_ERR_ARG, "need N, row, col >= 1");
+    if (N < 1 || row < 1 || row > 2048 || col < 1 || col > 1024) DFAIL(FNN_ERR_ARG, "need N >= 1, 1 <= row <= 2048, 1 <= col <= 1024");
     hipStream_t st = (hipStream_t)stream;
     double* dcost = nullptr;
     DHK(hipMalloc((void**)&dcost, 8));
-    DenseArgs a{W, bhid, bvis, X, N, row, col, lr, skip_last_update, dcost};
-    // register tilings (rows per wave x columns per lane); the smallest that holds [row][col]
-    if (row <= 16 * 4 && col <= 64) hipLaunchKernelGGL((k_dae_dense<4, 1>), dim3(1), dim3(1024), 0, st, a);
-    else if (row <= 16 * 8 && col <= 128) hipLaunchKernelGGL((k_dae_dense<8, 2>), dim3(1), dim3(1024), 0, st, a);
-    else if (row <= 16 * 19 && col <= 128) hipLaunchKernelGGL((k_dae_dense<19, 2>), dim3(1), dim3(1024), 0, st, a);
-    else if (row <= 16 * 13 && col <= 320) hipLaunchKernelGGL((k_dae_dense<13, 5>), dim3(1), dim3(1024), 0, st, a);
-    else { hipFree(dcost); DFAIL(FNN_ERR_ARG, "dae_dense_epoch: [row][col] must fit [304][128] or [208][320]"); }
+    const int CP = (col + 63) / 64 * 64;
+    const size_t lds = (size_t)(1024 + 2 * CP + 4 * row + 2) * sizeof(S) + 16 * 8;
+    DenseGArgs<S> a{W, bhid, bvis, X, N, row, col, lr, skip_last, dcost};
+    DHK(hipFuncSetAttribute((const void*)k_dae_dense_g<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_dae_dense_g<S>), dim3(1), dim3(1024), lds, st, a);
     DHK(hipGetLastError());
     double c = 0.0;
     DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
@@ -313,8 +429,8 @@ int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t 
     return FNN_OK;
 }
 
-int dae_bag_cumsum_sigmoid(const float* W0, const float* b0, int H, int64_t n_rows, const int32_t* ids, int n, int F, float* out,
-                           void* stream)
+template <typename S>
+int bag_cumsum_t(const S* W0, const S* b0, int H, int64_t n_rows, const int32_t* ids, int n, int F, S* out, void* stream)
 {
     if (!W0 || !b0 || !ids || !out) DFAIL(FNN_ERR_ARG, "null pointer");
     if (H < 1 || H > 1024 || n < 1 || F < 1) DFAIL(FNN_ERR_ARG, "need 1 <= H <= 1024, n >= 1, F >= 1");
@@ -322,11 +438,77 @@ int dae_bag_cumsum_sigmoid(const float* W0, const float* b0, int H, int64_t n_ro
     int* flag = g_flag(st);
     if (!flag) DFAIL(FNN_ERR_HIP, "hipMalloc failed");
     int bs = 64; while (bs < H) bs <<= 1;
-    hipLaunchKernelGGL(k_dae_bag_cumsum, dim3(n), dim3(bs), 0, st, W0, b0, H, n_rows, ids, n, F, out, flag);
+    hipLaunchKernelGGL((k_dae_bag_cumsum<S>), dim3(n), dim3(bs), 0, st, W0, b0, H, n_rows, ids, n, F, out, flag);
     DHK(hipGetLastError());
     const int bad = read_flag(flag, st);
     if (bad < 0) DFAIL(FNN_ERR_HIP, "stream synchronisation failed");
     if (bad) DFAIL(FNN_ERR_RANGE, "feature id outside [-1, n_rows)");
+    return FNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dae_sparse_epoch(const float* table, int64_t n_rows, float* bhid, float* bvis, float* bhid_prev, const int32_t* idx,
+                     const float* x, int64_t N, int H, int S, float lr, double* cost_sum_out, void* stream)
+{
+    return sparse_epoch_t<float>(table, n_rows, bhid, bvis, bhid_prev, idx, x, N, H, S, lr, cost_sum_out, stream);
+}
+int dae_sparse_epoch_f64(const double* table, int64_t n_rows, double* bhid, double* bvis, double* bhid_prev, const int32_t* idx,
+                         const double* x, int64_t N, int H, int S, double lr, double* cost_sum_out, void* stream)
+{
+    return sparse_epoch_t<double>(table, n_rows, bhid, bvis, bhid_prev, idx, x, N, H, S, lr, cost_sum_out, stream);
+}
+
+int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t N, int row, int col, float lr,
+                    int skip_last_update, double* cost_sum_out, void* stream)
+{
+    if (!W || !bhid || !bvis || !X) DFAIL(FNN_ERR_ARG, "null pointer");
+    if (N < 1 || row < 1 || col < 1) DFAIL(FNN_ERR_ARG, "need N, row, col >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    // register tilings (rows per wave x columns per lane); the smallest that holds [row][col]; anything
+    // larger takes the global-memory form of the same step
+    const bool fits = (row <= 64 && col <= 64) || (row <= 128 && col <= 128) || (row <= 304 && col <= 128) || (row <= 208 && col <= 320);
+    if (!fits) return dense_g_epoch_t<float>(W, bhid, bvis, X, N, row, col, lr, skip_last_update, cost_sum_out, stream);
+    double* dcost = nullptr;
+    DHK(hipMalloc((void**)&dcost, 8));
+    DenseArgs a{W, bhid, bvis, X, N, row, col, lr, skip_last_update, dcost};
+    if (row <= 16 * 4 && col <= 64) hipLaunchKernelGGL((k_dae_dense<4, 1>), dim3(1), dim3(1024), 0, st, a);
+    else if (row <= 16 * 8 && col <= 128) hipLaunchKernelGGL((k_dae_dense<8, 2>), dim3(1), dim3(1024), 0, st, a);
+    else if (row <= 16 * 19 && col <= 128) hipLaunchKernelGGL((k_dae_dense<19, 2>), dim3(1), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((k_dae_dense<13, 5>), dim3(1), dim3(1024), 0, st, a);
+    DHK(hipGetLastError());
+    double c = 0.0;
+    DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
+    DHK(hipStreamSynchronize(st));
+    hipFree(dcost);
+    if (cost_sum_out) *cost_sum_out = c;
+    return FNN_OK;
+}
+int dae_dense_epoch_f64(double* W, double* bhid, double* bvis, const double* X, int64_t N, int row, int col, double lr,
+                        int skip_last_update, double* cost_sum_out, void* stream)
+{
+    return dense_g_epoch_t<double>(W, bhid, bvis, X, N, row, col, lr, skip_last_update, cost_sum_out, stream);
+}
+
+int dae_bag_cumsum_sigmoid(const float* W0, const float* b0, int H, int64_t n_rows, const int32_t* ids, int n, int F, float* out,
+                           void* stream)
+{
+    return bag_cumsum_t<float>(W0, b0, H, n_rows, ids, n, F, out, stream);
+}
+int dae_bag_cumsum_sigmoid_f64(const double* W0, const double* b0, int H, int64_t n_rows, const int32_t* ids, int n, int F, double* out,
+                               void* stream)
+{
+    return bag_cumsum_t<double>(W0, b0, H, n_rows, ids, n, F, out, stream);
+}
+
+int dae_affine_sigmoid_f64(const double* in, const double* W, const double* bias, int n, int a, int b, double* out, void* stream)
+{
+    if (!in || !W || !bias || !out || n < 1 || a < 1 || b < 1) DFAIL(FNN_ERR_ARG, "null pointer or empty shape");
+    const size_t cnt = (size_t)n * b;
+    hipLaunchKernelGGL(k_dae_affine_sigmoid_f64, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, W, bias, n, a, b, out);
+    DHK(hipGetLastError());
     return FNN_OK;
 }
 

@@ -67,9 +67,12 @@ def sampled_visibles(rs, lines, row, k=2):
     return idx, x
 
 
-def get_da_weights(file, arr, ncases, num_feats=16, batch_size=100000, epochs=3, learning_rate=0.1, device=0):
+def get_da_weights(file, arr, ncases, num_feats=16, batch_size=100000, epochs=3, learning_rate=0.1, device=0, precision='f64'):
     """:347-371.  arr = [x_dim, H0, H1, H2]; returns [W0, b0, W1, b1, W2, b2] (float64 arrays, as
-    python/SNN_DAE.py:83-86 pickles them)."""
+    python/SNN_DAE.py:83-86 pickles them).  precision 'f64' (default) is the reference's own
+    (theano.config.floatX): its online lr = 0.1 dynamics are sensitive enough that only an f64 run
+    tracks them over a whole pre-training; 'f32' keeps W of the dense layers in registers (faster,
+    step-level parity 1e-7, trajectories drift apart after a few thousand steps)."""
     import torch
     lib = _capi.load()
     dev = torch.device('cuda', device)
@@ -78,8 +81,14 @@ def get_da_weights(file, arr, ncases, num_feats=16, batch_size=100000, epochs=3,
     N, k = len(lines), 2
     n_fields = max(len(l[0]) for l in lines)
 
-    def t32(a):
-        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev).contiguous()
+    f64 = precision == 'f64'
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    sfx = '_f64' if f64 else ''
+    sparse_epoch, dense_epoch = getattr(lib, 'dae_sparse_epoch' + sfx), getattr(lib, 'dae_dense_epoch' + sfx)
+    bag_cumsum = getattr(lib, 'dae_bag_cumsum_sigmoid' + sfx)
+
+    def t32(a):                                               # host array -> device tensor of the working precision
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=npdt)).to(dev).contiguous()
 
     results, X = [], None
     for index in range(2, len(arr) + 1):
@@ -94,37 +103,40 @@ def get_da_weights(file, arr, ncases, num_feats=16, batch_size=100000, epochs=3,
             table = rs.uniform(low=-_bound(sparse_len, col), high=_bound(sparse_len, col), size=(sparse_len, col))   # :264-271
             rs.uniform(low=-_bound(row, col), high=_bound(row, col), size=(row, col))                  # the scratch W (:273-280)
             tab_d = t32(table)
-            bh = torch.zeros(col, dtype=torch.float32, device=dev)
-            bv = torch.zeros(row, dtype=torch.float32, device=dev)
-            bprev = torch.zeros(col, dtype=torch.float32, device=dev)
+            bh = torch.zeros(col, dtype=tdt, device=dev)
+            bv = torch.zeros(row, dtype=tdt, device=dev)
+            bprev = torch.zeros(col, dtype=tdt, device=dev)
             for ep in range(epochs):
                 idx, x = sampled_visibles(rs, lines, row, k)
-                idx_d, x_d = torch.as_tensor(idx).to(dev), torch.as_tensor(x).to(dev)
-                _check(lib, lib.dae_sparse_epoch(tab_d.data_ptr(), sparse_len, bh.data_ptr(), bv.data_ptr(), bprev.data_ptr(),
+                idx_d, x_d = torch.as_tensor(idx).to(dev), t32(x)
+                _check(lib, sparse_epoch(tab_d.data_ptr(), sparse_len, bh.data_ptr(), bv.data_ptr(), bprev.data_ptr(),
                                                  idx_d.data_ptr(), x_d.data_ptr(), N, col, row, learning_rate, C.byref(cost), st))
                 print('Training epoch %d, cost ' % ep, cost.value / N)
-            results += [table, bprev.cpu().numpy().astype(np.float64)]
+            results += [table if f64 else table.astype(np.float32).astype(np.float64), bprev.cpu().numpy().astype(np.float64)]
             act = np.full((N, n_fields), -1, np.int32)                     # ALL ids of the line (:173-176)
             for n, (ids, _) in enumerate(lines):
                 act[n, :len(ids)] = ids
-            X = torch.empty((N, col), dtype=torch.float32, device=dev)
+            X = torch.empty((N, col), dtype=tdt, device=dev)
             b0_d = t32(results[1])
             act_d = torch.as_tensor(act).to(dev)
-            _check(lib, lib.dae_bag_cumsum_sigmoid(tab_d.data_ptr(), b0_d.data_ptr(), col, sparse_len, act_d.data_ptr(), N,
+            _check(lib, bag_cumsum(tab_d.data_ptr(), b0_d.data_ptr(), col, sparse_len, act_d.data_ptr(), N,
                                                    n_fields, X.data_ptr(), st))
         else:
             W = t32(rs.uniform(low=-_bound(col, row), high=_bound(col, row), size=(row, col)))
-            bh = torch.zeros(col, dtype=torch.float32, device=dev)
-            bv = torch.zeros(row, dtype=torch.float32, device=dev)
+            bh = torch.zeros(col, dtype=tdt, device=dev)
+            bv = torch.zeros(row, dtype=tdt, device=dev)
             for ep in range(epochs):
-                _check(lib, lib.dae_dense_epoch(W.data_ptr(), bh.data_ptr(), bv.data_ptr(), X.data_ptr(), N, row, col,
+                _check(lib, dense_epoch(W.data_ptr(), bh.data_ptr(), bv.data_ptr(), X.data_ptr(), N, row, col,
                                                 learning_rate, 1 if ep == epochs - 1 else 0, C.byref(cost), st))
                 print('Training epoch %d, cost ' % ep, cost.value / N)
             results += [W.cpu().numpy().astype(np.float64), bh.cpu().numpy().astype(np.float64)]
             if index < len(arr):                                           # input of the next layer: sigmoid(X W + b)
-                Xn = torch.empty((N, col), dtype=torch.float32, device=dev)
-                _check_rbm(lib, lib.rbm_affine(X.data_ptr(), W.data_ptr(), bh.data_ptr(), N, row, col, Xn.data_ptr(), st))
-                _check_rbm(lib, lib.rbm_sigmoid(Xn.data_ptr(), Xn.numel(), st))
+                Xn = torch.empty((N, col), dtype=tdt, device=dev)
+                if f64:
+                    _check(lib, lib.dae_affine_sigmoid_f64(X.data_ptr(), W.data_ptr(), bh.data_ptr(), N, row, col, Xn.data_ptr(), st))
+                else:
+                    _check_rbm(lib, lib.rbm_affine(X.data_ptr(), W.data_ptr(), bh.data_ptr(), N, row, col, Xn.data_ptr(), st))
+                    _check_rbm(lib, lib.rbm_sigmoid(Xn.data_ptr(), Xn.numel(), st))
                 X = Xn
     torch.cuda.synchronize(dev)
     return results

@@ -38,7 +38,8 @@ int dae_sparse_epoch(const float* table, int64_t n_rows, float* bhid, float* bvi
  * layers): W [row, col], bhid [col], bvis [row] updated in place by N online steps
  * W -= lr (x (x) dy + d (x) y).  skip_last_update != 0: the last example only contributes its cost
  * (the reference returns the parameters as they were before the last call's update).
- * row <= 304, col <= 320 (W lives in the registers of one 1024-thread workgroup). */
+ * W lives in the registers of one 1024-thread workgroup when [row][col] fits [304][128] or [208][320];
+ * larger shapes (row <= 2048, col <= 1024) keep W in global memory. */
 int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t N, int row, int col,
                     float lr, int skip_last_update, double* cost_sum_out, void* stream);
 
@@ -47,6 +48,22 @@ int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t 
  * so unit k receives the running sum over units 0..k.  ids [n, F] int32, -1 = none.  H <= 1024. */
 int dae_bag_cumsum_sigmoid(const float* W0, const float* b0, int H, int64_t n_rows, const int32_t* ids,
                            int n, int F, float* out, void* stream);
+
+/* The same three steps in float64 -- the reference's own precision (theano.config.floatX).  Its
+ * lr = 0.1 online dynamics amplify a 1e-7 perturbation to O(1) within a few thousand steps at
+ * 200/300/100 hidden units, so only an f64 run tracks the reference's trajectory end to end.  W of
+ * the dense trainer stays in global memory here (any row <= 2048, col <= 1024); dae_dense_epoch
+ * takes the same path for f32 shapes its register tilings do not hold. */
+int dae_sparse_epoch_f64(const double* table, int64_t n_rows, double* bhid, double* bvis, double* bhid_prev,
+                         const int32_t* idx, const double* x, int64_t N, int H, int S, double lr,
+                         double* cost_sum_out, void* stream);
+int dae_dense_epoch_f64(double* W, double* bhid, double* bvis, const double* X, int64_t N, int row, int col,
+                        double lr, int skip_last_update, double* cost_sum_out, void* stream);
+int dae_bag_cumsum_sigmoid_f64(const double* W0, const double* b0, int H, int64_t n_rows, const int32_t* ids,
+                               int n, int F, double* out, void* stream);
+/* out [n, b] = sigmoid(in [n, a] . W [a, b] + bias [b]): the propagation between dense layers (:183-187). */
+int dae_affine_sigmoid_f64(const double* in, const double* W, const double* bias, int n, int a, int b,
+                           double* out, void* stream);
 
 #ifdef __cplusplus
 }
