@@ -22,6 +22,11 @@ thread_local std::string g_err;
 #define DHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e_); return FNN_ERR_HIP; } } while (0)
 #define DFAIL(code, msg) do { g_err = (msg); return (code); } while (0)
 
+struct DevDouble {                       // one device double, freed on every exit path
+    double* p = nullptr;
+    ~DevDouble() { if (p) hipFree(p); }
+};
+
 __device__ inline float sigm(float z) { return 1.0f / (1.0f + expf(-z)); }
 __device__ inline double sigm(double z) { return 1.0 / (1.0 + exp(-z)); }
 __device__ inline float wave_sum(float v) {
@@ -390,8 +395,9 @@ int sparse_epoch_t(const S* table, int64_t n_rows, S* bhid, S* bvis, S* bhid_pre
     hipStream_t st = (hipStream_t)stream;
     int* flag = g_flag(st);
     if (!flag) DFAIL(FNN_ERR_HIP, "hipMalloc failed");
-    double* dcost = nullptr;
-    DHK(hipMalloc((void**)&dcost, 8));
+    DevDouble dc;
+    DHK(hipMalloc((void**)&dc.p, 8));
+    double* dcost = dc.p;
     SparseArgs<S> a{table, n_rows, bhid, bvis, bhid_prev, idx, x, N, H, Sn, lr, dcost, flag};
     DHK(hipFuncSetAttribute((const void*)k_dae_sparse<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dae_sparse_lds<S>()));
     hipLaunchKernelGGL((k_dae_sparse<S>), dim3(1), dim3(256), dae_sparse_lds<S>(), st, a);
@@ -399,7 +405,6 @@ int sparse_epoch_t(const S* table, int64_t n_rows, S* bhid, S* bvis, S* bhid_pre
     double c = 0.0;
     DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
     const int bad = read_flag(flag, st);
-    hipFree(dcost);
     if (bad < 0) DFAIL(FNN_ERR_HIP, "stream synchronisation failed");
     if (bad) DFAIL(FNN_ERR_RANGE, "visible id outside [0, n_rows)");
     if (cost_sum_out) *cost_sum_out = c;
@@ -413,8 +418,9 @@ int dense_g_epoch_t(S* W, S* bhid, S* bvis, const S* X, int64_t N, int row, int 
     if (!W || !bhid || !bvis || !X) DFAIL(FNN_ERR_ARG, "null pointer");
     if (N < 1 || row < 1 || row > 2048 || col < 1 || col > 1024) DFAIL(FNN_ERR_ARG, "need N >= 1, 1 <= row <= 2048, 1 <= col <= 1024");
     hipStream_t st = (hipStream_t)stream;
-    double* dcost = nullptr;
-    DHK(hipMalloc((void**)&dcost, 8));
+    DevDouble dc;
+    DHK(hipMalloc((void**)&dc.p, 8));
+    double* dcost = dc.p;
     const int CP = (col + 63) / 64 * 64;
     const size_t lds = (size_t)(1024 + 2 * CP + 4 * row + 2) * sizeof(S) + 16 * 8;
     DenseGArgs<S> a{W, bhid, bvis, X, N, row, col, lr, skip_last, dcost};
@@ -424,7 +430,6 @@ int dense_g_epoch_t(S* W, S* bhid, S* bvis, const S* X, int64_t N, int row, int 
     double c = 0.0;
     DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
     DHK(hipStreamSynchronize(st));
-    hipFree(dcost);
     if (cost_sum_out) *cost_sum_out = c;
     return FNN_OK;
 }
@@ -471,8 +476,9 @@ int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t 
     // larger takes the global-memory form of the same step
     const bool fits = (row <= 64 && col <= 64) || (row <= 128 && col <= 128) || (row <= 304 && col <= 128) || (row <= 208 && col <= 320);
     if (!fits) return dense_g_epoch_t<float>(W, bhid, bvis, X, N, row, col, lr, skip_last_update, cost_sum_out, stream);
-    double* dcost = nullptr;
-    DHK(hipMalloc((void**)&dcost, 8));
+    DevDouble dc;
+    DHK(hipMalloc((void**)&dc.p, 8));
+    double* dcost = dc.p;
     DenseArgs a{W, bhid, bvis, X, N, row, col, lr, skip_last_update, dcost};
     if (row <= 16 * 4 && col <= 64) hipLaunchKernelGGL((k_dae_dense<4, 1>), dim3(1), dim3(1024), 0, st, a);
     else if (row <= 16 * 8 && col <= 128) hipLaunchKernelGGL((k_dae_dense<8, 2>), dim3(1), dim3(1024), 0, st, a);
@@ -482,7 +488,6 @@ int dae_dense_epoch(float* W, float* bhid, float* bvis, const float* X, int64_t 
     double c = 0.0;
     DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
     DHK(hipStreamSynchronize(st));
-    hipFree(dcost);
     if (cost_sum_out) *cost_sum_out = c;
     return FNN_OK;
 }

@@ -653,3 +653,31 @@ def test_eval_metrics_equal_sklearn(built):
     with pytest.raises(FNNError):                                           # roc_auc_score: ValueError
         eng.evaluate(ids[:100], np.zeros(100, np.int32))
     eng.close()
+
+
+def test_train_step_with_64bit_sort_keys(built):
+    """A table of 1,100,000 rows makes n_rows * 4096 exceed 2^32, so the grouping runs on 64-bit
+    (row << 32 | t) keys: two steps (the second with an announced batch, i.e. the run sort + rank merge
+    roles inside the step launches) against the oracle, with duplicates and rows near the top of the range."""
+    B = 700
+    rows, fo, ids, y, p, r1, r2 = make_problem(2 * B, n_rows=1100000, seed=23)
+    top = rows.shape[0] - 1
+    ids[5, 15] = top; ids[9, 15] = top; ids[B + 3, 15] = top                # the very last row, repeated
+    eng = make_engine(rows, fo, p, lr=0.01, lam1=0.0, lamfm=0.1)
+    import torch
+    ids_d = torch.as_tensor(ids).to(eng.device).contiguous()
+    rows64 = rows.astype(np.float64).copy()
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    for step in range(2):
+        sl = slice(step * B, (step + 1) * B)
+        if step == 0:
+            eng.prefetch_ids(ids_d[B:2 * B])
+        eng.train_step(ids_d[sl], y[sl], r1, r2, want_loss=False)
+        x = orc.gather(rows64, ids[sl], -3.0)
+        gx, _, _, _, _ = orc.train_call(p64, x, y[sl].astype(np.float64), r1.astype(np.float64), r2.astype(np.float64), 0.01, 0.0)
+        orc.scatter_sgd(rows64, ids[sl], gx, 0.01, 0.1)
+    touched = np.unique(ids[ids >= 0])
+    change = np.abs(rows64[touched] - rows[touched]).max()
+    assert np.abs(eng.get_rows(touched) - rows64[touched]).max() <= 2e-3 * change + 2e-7      # two f32 steps
+    assert eng.lib.fnn_sync(eng.h) == 0
+    eng.close()
