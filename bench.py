@@ -55,14 +55,17 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn'],
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather'],
                     help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
-                         'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack)')
+                         'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
+                         'gather: the standalone embedding gathers (A3: FM rows; A8: 200-wide bag rows) against the HBM roofline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
     if args.workload == 'ipnn':
         return bench_ipnn(args)
+    if args.workload == 'gather':
+        return bench_gather(args)
 
     import torch
     import deep_ctr_amd  # noqa: F401
@@ -234,6 +237,72 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_gather(args):
+    """The embedding gathers alone, 16,384 examples per launch (fnn_gather, reference-shaped output):
+    A3 -- 16 FM rows of 44 B -> x [177] f32 (python/FNN_wnzh.py:87-96): 64 + 704 + 708 = 1,476 algorithmic
+    bytes per example, from a 60 MB table (Infinity-Cache resident);
+    A8 -- sigmoid(sum of 16 bag rows of 800 B + bias) -> x [200] f32 (python/SNN_RBM.py:238-262):
+    64 + 12,800 + 800 = 13,664 B per example from a 750 MB table: the HBM-bound gather."""
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import _capi, synth
+    from deep_ctr_amd.engine import FNNEngine
+    B, NB, H0 = 16384, 8, 200
+    dev = torch.device('cuda', 0)
+    sizes = synth.field_sizes_ipinyou()
+    fo = synth.field_of_row(sizes)
+    off_f = np.cumsum([0] + sizes[:-1])
+    ids_by = {'zipf': synth.zipf_ids(NB * B, sizes, 1.1, 1234),            # the step benchmark's ids: hot rows hit L2 / Infinity Cache
+              'uniform': (off_f + (np.random.default_rng(7).random((NB * B, F)) * np.asarray(sizes)).astype(np.int64)).astype(np.int32)}
+    res = {}
+    for name, per_ex, dist in (('fm', 64 + 704 + 708, 'zipf'), ('bag', 64 + 16 * 800 + 800, 'uniform'), ('bag_zipf', 64 + 16 * 800 + 800, 'zipf')):
+        ids = torch.as_tensor(ids_by[dist]).to(dev).contiguous()
+        if name == 'fm':
+            eng = FNNEngine(F, K, H1, H2, max_batch=B, precision='bf16', device=0)
+            eng.set_table(synth.fm_table(sum(sizes), K, 0.05, 1234), fo, -3.0)
+            xdim = XDIM
+        else:
+            eng = FNNEngine(F, 0, H1, H2, max_batch=B, precision='bf16', device=0, mode='bag', hidden0=H0)
+            eng.set_table(np.random.default_rng(1).standard_normal((sum(sizes), H0), dtype=np.float32) * np.float32(0.05), fo, 0.0)
+            eng.set_bag_bias(np.zeros(H0, np.float32))
+            xdim = H0
+        Bk = B
+        x = torch.empty((Bk, xdim), dtype=torch.float32, device=dev)
+        lib, h = eng.lib, eng.h
+
+        def run(n):
+            for i in range(n):
+                off = (i * Bk) % (NB * B - Bk + 1)
+                rc = lib.fnn_gather(h, ids.data_ptr() + off * F * 4, Bk, x.data_ptr(), _capi.FNN_MEM_DEVICE)
+                if rc != 0:
+                    raise RuntimeError(lib.fnn_last_error(h).decode())
+        with torch.cuda.stream(eng.stream):
+            run(args.warmup)
+            eng.sync()
+            eng.prof_enable(True); eng.prof_reset()
+            t0 = time.perf_counter()
+            run(args.steps)
+            eng.sync()
+            dt = time.perf_counter() - t0
+        ms = eng.prof_get('gather_ref')[0]
+        eng.prof_enable(False)
+        ach = per_ex * Bk / (ms * 1e-3) / 1e9
+        res[name] = {'ids': dist, 'examples_per_launch': Bk, 'avg_launch_ms': ms, 'wall_ms_per_launch': dt / args.steps * 1e3,
+                     'algorithmic_per_example': per_ex, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                     'examples_per_sec': Bk / (ms * 1e-3)}
+        eng.close()
+    print(json.dumps({
+        'metric': 'examples/sec', 'value': res['fm']['examples_per_sec'], 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': res['fm']['avg_launch_ms'], 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'standalone embedding gathers: FM rows (16 x 44 B -> x[177]) and SNN bag (16 x 800 B -> x[200]), '
+                               '937670 rows, Zipf(1.1) ids'},
+        'roofline': dict(res['bag'], kernel='k_bag_ref (A8 gather, uniform ids: every row read misses the caches)', bound='hbm',
+                         traffic=None),
+        'bag_gather_zipf': res['bag_zipf'], 'fm_gather': res['fm'],
+        'cpu_baseline': None}))
 
 
 IP_HIDDEN = [1000, 800, 600, 400, 200, 100, 50]        # python/baseline.py:139 (FNN_IP_L7)

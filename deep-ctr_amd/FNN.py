@@ -117,6 +117,9 @@ def run(argv, out=None):
             y = train_yf_d[lo:lo + batch_size]
             if j == n_batch - 1:
                 pre_step = eng.get_dense()                     # `train` returns PRE-update tensors (:298)
+            nlo = (j + 1) * batch_size                         # announce the next batch: its grouping rides on this step's launches
+            if j + 1 < n_batch and nlo + 1 <= train_size and len(y) <= 4096:
+                eng.prefetch_ids(train_ids_d[nlo:nlo + batch_size])
             eng.train_step(ids, y, r1.draw()[0], r2.draw()[0], b_size=len(y), want_loss=False)
         eng.sync()
         print('training: ' + fmt_time(time.time() - start_time))

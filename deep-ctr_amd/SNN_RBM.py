@@ -134,6 +134,9 @@ def run(argv, kind='rbm'):
     def fmt_time(t):
         return str(int(t / 60)) + 'm ' + str(int(t % 60)) + 's'
 
+    train_ids_d, train_y_d = eng.to_device(train_ids, train_y)   # resident in HBM: no per-batch copies, no per-epoch parsing
+    test_ids_d, test_y_d = eng.to_device(test_ids, test_y)
+    train_yf_d = train_y_d.float()
     print("Training model:")                                   # mytrain, :269-323
     min_err = 0
     min_err_epoch = 0
@@ -143,16 +146,18 @@ def run(argv, kind='rbm'):
         start_time = time.time()
         for j in range(n_batch):
             lo = j * batch_size
-            eng.train_step(train_ids[lo:lo + batch_size], train_y[lo:lo + batch_size], r1.draw()[0], r2.draw()[0],
+            if j + 1 < n_batch:                                # announce the next batch (grouped beside this step's work)
+                eng.prefetch_ids(train_ids_d[lo + batch_size:lo + 2 * batch_size])
+            eng.train_step(train_ids_d[lo:lo + batch_size], train_yf_d[lo:lo + batch_size], r1.draw()[0], r2.draw()[0],
                            want_loss=False)
         eng.sync()
         print('training: ' + fmt_time(time.time() - start_time))
         start_time = time.time()
-        auc, rmse, ll = auc_rmse(train_ids, train_y)
+        auc, rmse, ll = auc_rmse(train_ids_d, train_y_d)
         log_p('\t\tTraining Err: \t' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
         print('training error: ' + fmt_time(time.time() - start_time))
         start_time = time.time()
-        auc, rmse, ll = auc_rmse(test_ids, test_y)
+        auc, rmse, ll = auc_rmse(test_ids_d, test_y_d)
         log_p('Test Err:' + str(i) + '\t' + str(auc) + '\t' + str(rmse))
         log_p('Test logloss:' + str(i) + '\t' + str(ll))
         print('test error: ' + fmt_time(time.time() - start_time))

@@ -428,8 +428,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     *out = nullptr;
     if (cfg->n_fields < 2 || cfg->n_fields > 64) { g_create_err = "n_fields must be in [2, 64]"; return FNN_ERR_ARG; }
     if (cfg->mode != FNN_MODE_FM && cfg->mode != FNN_MODE_BAG) { g_create_err = "bad mode"; return FNN_ERR_ARG; }
-    if (cfg->mode == FNN_MODE_BAG && (cfg->h0 < 4 || cfg->h0 > 252 || cfg->h0 % 4 != 0 || cfg->max_batch > 4096)) {
-        g_create_err = "FNN_MODE_BAG: h0 must be a multiple of 4 in [4, 252] and max_batch <= 4096"; return FNN_ERR_ARG; }
+    if (cfg->mode == FNN_MODE_BAG && (cfg->h0 < 4 || cfg->h0 > 252 || cfg->h0 % 4 != 0)) {
+        g_create_err = "FNN_MODE_BAG: h0 must be a multiple of 4 in [4, 252]"; return FNN_ERR_ARG; }
     if (cfg->mode == FNN_MODE_FM && (cfg->k < 1 || cfg->k > 15)) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
     if (cfg->hidden1 < 1 || cfg->hidden1 > 4095 || cfg->hidden2 < 1 || cfg->hidden2 > 255) { g_create_err = "hidden1 must be in [1, 4095], hidden2 in [1, 255]"; return FNN_ERR_ARG; }
     if (cfg->max_batch < 1 || cfg->max_batch > 16384) { g_create_err = "max_batch must be in [1, 16384] (per-field LDS sort)"; return FNN_ERR_ARG; }
@@ -756,7 +756,7 @@ int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memki
     {
         ProfScope ps(h, "gather_ref", h->st);
         if (h->bag)
-            hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
+            hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
                                h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag);
         else
             hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,

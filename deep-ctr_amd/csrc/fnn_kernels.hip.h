@@ -1288,20 +1288,35 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
     }
 }
 
-// reference-shaped outputs of the bag path: x [B][H0] = sigmoid(bag) and the raw gx [B][H0]
-static __global__ void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw, const float* __restrict__ table,
-                          int64_t n_rows, const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err)
+// reference-shaped output of the bag path: x [B][H0] = sigmoid(sum of the F rows + bb0)
+// (python/SNN_RBM.py:248-256).  One thread = 16 bytes of one example's output: its F row pieces are
+// F independent 16-byte loads in flight (the ids of an example are the same for all its threads:
+// L1 broadcast); consecutive threads read consecutive pieces of the same 800-byte rows.
+static __global__ __launch_bounds__(256) void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw,
+                                                         const float* __restrict__ table, int64_t n_rows,
+                                                         const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err)
 {
+    const int nq = rw >> 2;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)B * rw) return;
-    const int t = (int)(gid / rw), c = (int)(gid % rw);
-    float s = bb0[c];
-    for (int f = 0; f < F; ++f) {
-        int64_t id = ids[(size_t)t * F + f];
-        if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
-        if (id >= 0) s += table[(size_t)id * rw + c];
+    if (gid >= (size_t)B * nq) return;
+    const int t = (int)(gid / nq), c4 = (int)(gid % nq);
+    float4 acc = *reinterpret_cast<const float4*>(bb0 + 4 * c4);
+    for (int f0 = 0; f0 < F; f0 += 16) {
+        int64_t id[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            id[u] = (f0 + u < F) ? ids[(size_t)t * F + f0 + u] : -1;
+            if (id[u] < -1 || id[u] >= n_rows) { atomicOr(err, 1); id[u] = -1; }
+        }
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            v[u] = id[u] >= 0 ? *reinterpret_cast<const float4*>(table + (size_t)id[u] * rw + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    x[gid] = 1.0f / (1.0f + expf(-s));
+    *reinterpret_cast<float4*>(x + (size_t)t * rw + 4 * c4) =
+        make_float4(1.0f / (1.0f + expf(-acc.x)), 1.0f / (1.0f + expf(-acc.y)), 1.0f / (1.0f + expf(-acc.z)), 1.0f / (1.0f + expf(-acc.w)));
 }
 static __global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, int n)
 {
