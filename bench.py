@@ -253,9 +253,9 @@ def bench_gather(args):
     dev = torch.device('cuda', 0)
     sizes = synth.field_sizes_ipinyou()
     fo = synth.field_of_row(sizes)
-    off_f = np.cumsum([0] + sizes[:-1])
     ids_by = {'zipf': synth.zipf_ids(NB * B, sizes, 1.1, 1234),            # the step benchmark's ids: hot rows hit L2 / Infinity Cache
-              'uniform': (off_f + (np.random.default_rng(7).random((NB * B, F)) * np.asarray(sizes)).astype(np.int64)).astype(np.int32)}
+              # every slot draws from the WHOLE table (the bag gather ignores fields): 262k distinct 800-byte rows per launch
+              'uniform': np.random.default_rng(7).integers(0, sum(sizes), (NB * B, F), dtype=np.int64).astype(np.int32)}
     res = {}
     for name, per_ex, dist in (('fm', 64 + 704 + 708, 'zipf'), ('bag', 64 + 16 * 800 + 800, 'uniform'), ('bag_zipf', 64 + 16 * 800 + 800, 'zipf')):
         ids = torch.as_tensor(ids_by[dist]).to(dev).contiguous()
