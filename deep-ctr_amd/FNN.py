@@ -19,6 +19,7 @@ import deep_ctr_amd  # noqa: E402,F401
 from deep_ctr_amd import dl_utils as ut  # noqa: E402
 from deep_ctr_amd.data_fm import DataFM  # noqa: E402
 from deep_ctr_amd.engine import FNNEngine  # noqa: E402
+from deep_ctr_amd.ipnn import FNN  # noqa: E402,F401  (the TensorFlow-style class of the same name, python/FNN.py:4)
 
 
 def run(argv, out=None):

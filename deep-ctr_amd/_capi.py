@@ -79,7 +79,7 @@ RBM_SIGNATURES = {
 
 class ipnn_cfg(C.Structure):
     _fields_ = [("n_fields", C.c_int32), ("k", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8),
-                ("act", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32), ("lr", C.c_float),
+                ("act", C.c_int32), ("pairs", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32), ("lr", C.c_float),
                 ("keep_prob", C.c_float), ("device", C.c_int32), ("stream", C.c_void_p)]
 
 

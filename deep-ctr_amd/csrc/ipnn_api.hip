@@ -47,6 +47,7 @@ __device__ inline float ip_dact_u(float u, int act) {
 // A operand) and a0T (rows = columns, k = examples: the weight-gradient product's A operand).
 // ------------------------------------------------------------------------------------------
 struct IpFwdArgs {
+    int P;                      // pair products: F (F - 1) / 2 (FNN_IP_L*) or 0 (the plain FNN class, python/FNN.py:80)
     const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; const float* b;
     const uint8_t* mask; int d0; float inv_keep; int act; int D0p, ldT; int* err;
 };
@@ -58,7 +59,7 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
     float* se = reinterpret_cast<float*>(smem);                 // [16][F*16] raw embeddings
     float* sa = se + 16 * a.F * SLOT;                           // [16][D0p]  a0 values
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
-    const int P = F * (F - 1) / 2, CB = FS + P;
+    const int P = a.P, CB = FS + P;
     for (int e = tid; e < 16 * F * 4; e += 256) {               // gather: (example, field, quarter)
         const int q = e & 3, f = (e >> 2) % F, r = (e >> 2) / F, t = t0 + r;
         int64_t id = -1;
@@ -102,7 +103,7 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
 // Inner-product layer, backward: dz1' [Ba][D0p] f32 (already times mask/keep and act') ->
 // slot-layout embedding gradients gx' [Ba][D0p] (columns 16f + l) for the sparse-row update, and the
 // per-workgroup partial of db = sum_t dz1[b].
-struct IpBwdArgs { const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; int D0p; };
+struct IpBwdArgs { int P; const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; int D0p; };
 
 static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const float* __restrict__ dz, float* __restrict__ gxp,
                                                         float* __restrict__ gb_part)
@@ -111,7 +112,7 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
     float* se = reinterpret_cast<float*>(smem);                 // [16][F*16]
     float* sd = se + 16 * a.F * SLOT;                           // [16][D0p]
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
-    const int P = F * (F - 1) / 2, CB = FS + P;
+    const int P = a.P, CB = FS + P;
     for (int e = tid; e < 16 * F * 4; e += 256) {
         const int q = e & 3, f = (e >> 2) % F, r = (e >> 2) / F, t = t0 + r;
         int64_t id = -1;
@@ -128,7 +129,7 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
         if (l < K) {
             g = sd[r * a.D0p + c];
             // pair (i, j), i < j, sits at FS + i*(2F - i - 1)/2 + (j - i - 1)
-            for (int j = 0; j < F; ++j) {
+            for (int j = 0; j < (P ? F : 0); ++j) {
                 if (j == f) continue;
                 const int i0 = f < j ? f : j, j0 = f < j ? j : f;
                 const int n = i0 * (2 * F - i0 - 1) / 2 + (j0 - i0 - 1);
@@ -360,7 +361,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     }
     {
         IpProf ps(h, "ip_fwd");
-        IpFwdArgs fa{ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
+        IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag};
         hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0]);
     }
@@ -430,7 +431,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     }
     {
         IpProf ps(h, "ip_bwd");
-        IpBwdArgs ba{ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0]};
+        IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0]};
         hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, h->st, ba, h->dz0, h->gxp, h->gb_part);
     }
     {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
@@ -475,7 +476,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_ip_err = "no HIP device (libfnn_hip.so has no CPU fallback)"; return FNN_ERR_HIP; }
     ipnn_handle* h = new ipnn_handle();
     h->cfg = *cfg; h->dev = cfg->device; h->F = cfg->n_fields; h->K = cfg->k; h->L = cfg->n_hidden;
-    h->P = h->F * (h->F - 1) / 2; h->CB = h->F * SLOT + h->P; h->bf16 = cfg->precision == FNN_PREC_BF16;
+    h->P = cfg->pairs ? h->F * (h->F - 1) / 2 : 0; h->CB = h->F * SLOT + h->P; h->bf16 = cfg->precision == FNN_PREC_BF16;
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     auto fail = [&](int code) { g_ip_err = h->err; ipnn_destroy(h); return code; };
 #define IK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e2_); return fail(FNN_ERR_HIP); } } while (0)

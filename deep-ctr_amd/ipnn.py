@@ -14,7 +14,8 @@ from .engine import FNNError
 
 
 class IPNNEngine(object):
-    def __init__(self, n_fields, k, hidden, act='relu', max_batch=4096, precision='bf16', lr=1e-4, keep_prob=0.5, device=0):
+    def __init__(self, n_fields, k, hidden, act='relu', max_batch=4096, precision='bf16', lr=1e-4, keep_prob=0.5, device=0,
+                 pairs=True):
         import torch
         if not torch.cuda.is_available():
             raise FNNError(_capi.FNN_ERR_HIP, "no HIP device visible to PyTorch-ROCm; no CPU fallback")
@@ -22,9 +23,9 @@ class IPNNEngine(object):
         self.device = torch.device('cuda', device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.F, self.K, self.hidden = n_fields, k, list(hidden)
-        self.d = [n_fields * k + n_fields * (n_fields - 1) // 2 + 1] + self.hidden + [1]
+        self.d = [n_fields * k + (n_fields * (n_fields - 1) // 2 if pairs else 0) + 1] + self.hidden + [1]
         hid = (C.c_int32 * 8)(*(self.hidden + [0] * (8 - len(self.hidden))))
-        cfg = _capi.ipnn_cfg(n_fields, k, len(self.hidden), hid, _capi.IPNN_ACTS[act], max_batch,
+        cfg = _capi.ipnn_cfg(n_fields, k, len(self.hidden), hid, _capi.IPNN_ACTS[act], 1 if pairs else 0, max_batch,
                              1 if precision == 'bf16' else 0, lr, keep_prob, device, C.c_void_p(self.stream.cuda_stream))
         h = C.c_void_p()
         rc = self.lib.ipnn_create(C.byref(cfg), C.byref(h))
@@ -128,6 +129,7 @@ class _IPFamily(object):
     h1.., act_func]; _init_argv = ['uniform', lo, hi, seeds, path] (python/tf_util.py:41-82: a
     pickle path seeds any subset of the variables); _ptmzr_argv = ['sgd', lr, ...]."""
     N_HIDDEN = 0
+    PAIRS = True
 
     def __init__(self, cat_sizes, offsets, batch_size, _rch_argv, _init_argv, _ptmzr_argv, _reg_argv, mode='train',
                  eval_size=0, precision='bf16'):
@@ -138,7 +140,7 @@ class _IPFamily(object):
             raise NotImplementedError("only plain SGD is built (the reference's Adam/FTRL: python/tf_util.py:15-29)")
         self.keep = _reg_argv[0] if mode == 'train' else 1.0
         self.eng = IPNNEngine(X_feas, rank + 1, hidden, act, max_batch=max(batch_size, eval_size, 1), precision=precision,
-                              lr=_ptmzr_argv[1], keep_prob=self.keep)
+                              lr=_ptmzr_argv[1], keep_prob=self.keep, pairs=self.PAIRS)
         lo, hi, seeds, path = _init_argv[1], _init_argv[2], _init_argv[3], _init_argv[-1]
         var_map = pickle.load(open(path, 'rb')) if path else {}
         d = self.eng.d
@@ -187,3 +189,11 @@ class FNN_IP_L5(_IPFamily):
 
 class FNN_IP_L7(_IPFamily):
     N_HIDDEN = 7
+
+
+class FNN(_IPFamily):
+    """The reference's plain TensorFlow `FNN` class (python/FNN.py:5-101): z1 = [e_0 .. e_{F-1} | b], two
+    hidden layers, activation and inverted dropout before every matmul; var_map keys W, V, b, h1_w .. h3_b.
+    (Its Criteo numeric fields -- a value times a row, :78 -- are not built: categorical fields only.)"""
+    N_HIDDEN = 2
+    PAIRS = False

@@ -31,6 +31,8 @@ typedef struct ipnn_cfg {
     int32_t n_hidden;                  /* 3, 5 or 7 (any 1..8)                               */
     int32_t hidden[IPNN_MAX_HIDDEN];   /* e.g. 1000,800,600,400,200,100,50 (baseline.py:139) */
     int32_t act;                       /* IPNN_ACT_*                                         */
+    int32_t pairs;                     /* 1: z1 = [e | p | b] (FNN_IP_L*, FNN_IP_L7.py:108-114);
+                                          0: z1 = [e | b], the plain `FNN` class (python/FNN.py:80) */
     int32_t max_batch;                 /* <= 4096                                            */
     int32_t precision;                 /* FNN_PREC_F32 / FNN_PREC_BF16                       */
     float   lr;

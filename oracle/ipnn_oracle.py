@@ -33,15 +33,19 @@ def dact(x, name):
     return s * (1 - s)
 
 
+USE_PAIRS = True      # False: z1 = [e | b], the plain TensorFlow `FNN` class (python/FNN.py:76-94)
+
+
 def pairs(F):
-    return [(i, j) for i in range(F - 1) for j in range(i + 1, F)]
+    return [(i, j) for i in range(F - 1) for j in range(i + 1, F)] if USE_PAIRS else []
 
 
 def z1_of(table, b, ids):
     """ids [B, F] (one id per field).  Returns (e [B,F,K], z1 [B, F*K + F(F-1)/2 + 1])."""
     e = table[ids]
     B, F, K = e.shape
-    p = np.stack([(e[:, i] * e[:, j]).sum(axis=1) for (i, j) in pairs(F)], axis=1)
+    p = (np.stack([(e[:, i] * e[:, j]).sum(axis=1) for (i, j) in pairs(F)], axis=1) if pairs(F)
+         else np.zeros((B, 0)))
     return e, np.concatenate([e.reshape(B, F * K), p, np.full((B, 1), float(b))], axis=1)
 
 

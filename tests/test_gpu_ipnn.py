@@ -73,3 +73,44 @@ def test_ipnn_bf16_and_family_class(built, tmp_path):
     vm = pickle.load(open(tmp_path / 'm.pickle', 'rb'))
     assert set(vm) == {'W', 'V', 'b', 'h1_w', 'h1_b', 'h2_w', 'h2_b', 'h3_w', 'h3_b', 'h4_w', 'h4_b'}
     assert vm['V'].shape == (table.shape[0], K - 1) and vm['h1_w'].shape == (297, 400)
+
+
+def test_plain_fnn_class_without_pair_products(built, tmp_path):
+    """The reference's plain TensorFlow `FNN` class (python/FNN.py): z1 = [e | b], two hidden layers,
+    activation and inverted dropout before every matmul -- the same kernels with the pair products
+    switched off (ipnn_cfg.pairs = 0), against the oracle with USE_PAIRS = False."""
+    import pickle
+    from deep_ctr_amd.ipnn import FNN
+    rng = np.random.RandomState(8)
+    sizes = synth.field_sizes_tiny(600)
+    table = f32r(rng.standard_normal((sum(sizes), K)) * 0.2)
+    B, hidden = 200, [48, 20]
+    ids = synth.zipf_ids(B, sizes, 1.1, 9)
+    y = (rng.uniform(size=B) < 0.3).astype(np.float64)
+    d = [F * K + 1] + hidden + [1]
+    params = {'b': float(np.float32(0.1)), 'W': [f32r(rng.uniform(-0.3, 0.3, (d[i], d[i + 1]))) for i in range(3)],
+              'bias': [f32r(rng.uniform(-0.1, 0.1, d[i + 1])) for i in range(3)]}
+    masks = [(rng.uniform(size=(B, d[t])) < 0.8).astype(np.uint8) for t in range(3)]
+    m = FNN(None, None, B, [table.shape[0], F, K - 1] + hidden + ['tanh'], ['uniform', -0.01, 0.01, [1, 2, 3, 4, 5], None],
+            ['sgd', 0.01], [0.8], 'train', 0, precision='f32')
+    assert m.eng.d == d
+    m.eng.set_params(table, params['b'], params['W'], params['bias'])
+    io.USE_PAIRS = False
+    try:
+        np.testing.assert_allclose(m.forward(ids).cpu().numpy(), io.predict(params, table, ids, 'tanh'), rtol=2e-4, atol=1e-6)
+        out = m.eng.train_step(ids, y, masks, want_logits=True)
+        t0, W0 = table.copy(), [w.copy() for w in params['W']]
+        loss, logits, g = io.sgd_step(params, table, ids, y, 'tanh', 0.01, [mk.astype(np.float64) for mk in masks], 0.8)
+    finally:
+        io.USE_PAIRS = True
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=2e-4, atol=2e-5)
+    assert abs(out['loss'] - loss) <= 5e-5 * max(1.0, abs(loss))
+    b, Ws, bs = m.eng.get_params()
+    for t in range(3):
+        cw = np.abs(params['W'][t] - W0[t]).max() + 1e-12
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 2e-3 * cw + 2e-7
+    touched = np.unique(ids)
+    assert np.abs(m.eng.get_rows(touched) - table[touched]).max() <= 2e-3 * np.abs(table - t0).max() + 2e-7
+    m.dump(str(tmp_path / 'fnn.pickle'))
+    vm = pickle.load(open(tmp_path / 'fnn.pickle', 'rb'))
+    assert set(vm) == {'W', 'V', 'b', 'h1_w', 'h1_b', 'h2_w', 'h2_b', 'h3_w', 'h3_b'} and vm['h1_w'].shape == (F * K + 1, 48)
