@@ -80,7 +80,8 @@ RBM_SIGNATURES = {
 class ipnn_cfg(C.Structure):
     _fields_ = [("n_fields", C.c_int32), ("k", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 8),
                 ("act", C.c_int32), ("pairs", C.c_int32), ("max_batch", C.c_int32), ("precision", C.c_int32), ("lr", C.c_float),
-                ("keep_prob", C.c_float), ("device", C.c_int32), ("stream", C.c_void_p)]
+                ("keep_prob", C.c_float), ("optimizer", C.c_int32), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
+                ("adam_eps", C.c_float), ("device", C.c_int32), ("stream", C.c_void_p)]
 
 
 IPNN_ACTS = {'tanh': 0, 'sigmoid': 1, 'relu': 3}

@@ -7,6 +7,7 @@
 // own for the inner-product layer.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -256,6 +257,28 @@ static __global__ void k_ip_update(float* __restrict__ W, const float* __restric
     wf[ft_off<T>(c, r, Din)] = (T)w;
     wb[ft_off<T>(r, c, Dout)] = (T)w;
 }
+__device__ inline float adam_step(float w, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    return w - lr_t * m / (sqrtf(v) + eps);
+}
+
+// Adam on the embedding table: TensorFlow's gradient through concat / slice is DENSE (zero for
+// untouched rows), so every row's moments decay and every row moves each step -- one streaming pass
+// over table, m, v and the per-row gradient sums G (which it zeroes again for the next step).
+static __global__ void k_adam_table(float* __restrict__ tab, float* __restrict__ m, float* __restrict__ v, float* __restrict__ G,
+                                    size_t n, float lr_t, float b1, float b2, float eps)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 w = *reinterpret_cast<float4*>(tab + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+    const float4 g = *reinterpret_cast<const float4*>(G + i);
+    w.x = adam_step(w.x, g.x, mm.x, vv.x, lr_t, b1, b2, eps); w.y = adam_step(w.y, g.y, mm.y, vv.y, lr_t, b1, b2, eps);
+    w.z = adam_step(w.z, g.z, mm.z, vv.z, lr_t, b1, b2, eps); w.w = adam_step(w.w, g.w, mm.w, vv.w, lr_t, b1, b2, eps);
+    *reinterpret_cast<float4*>(tab + i) = w; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+    *reinterpret_cast<float4*>(G + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // One launch for the whole stack: W_t <- W_t - lr * (sum of its split-K slabs), both tiled shadows
 // refreshed; the last workgroup applies the bias-of-z1 gradient and reduces the per-example losses.
 struct IpUpdArgs {
@@ -264,7 +287,11 @@ struct IpUpdArgs {
     int Din[IPNN_MAX_HIDDEN + 1], Dout[IPNN_MAX_HIDDEN + 1], sk[IPNN_MAX_HIDDEN + 1]; int n;
     const float* slab; size_t zstride; float lr;
     float* b; const float* gb_part; int ngb; const float* loss_t; int Ba; float* loss_sum;
+    // Adam (python/tf_util.py:17-20, TensorFlow's AdamOptimizer): first / second moments beside every tensor;
+    // lr is then lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) of this step
+    int adam; float beta1, beta2, eps; float* Wm[IPNN_MAX_HIDDEN + 1]; float* Wv[IPNN_MAX_HIDDEN + 1]; float* bmv;
 };
+
 template <typename T>
 static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
 {
@@ -278,7 +305,11 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
             if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sg[threadIdx.x] += sg[threadIdx.x + o]; }
             __syncthreads();
         }
-        if (threadIdx.x == 0) { *u.loss_sum = sl[0]; *u.b -= u.lr * sg[0]; }
+        if (threadIdx.x == 0) {
+            *u.loss_sum = sl[0];
+            if (u.adam) *u.b = adam_step(*u.b, sg[0], u.bmv[0], u.bmv[1], u.lr, u.beta1, u.beta2, u.eps);
+            else *u.b -= u.lr * sg[0];
+        }
         return;
     }
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -289,7 +320,12 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     const size_t j = i - u.off[t];
     float g = 0.f;
     for (int z = 0; z < u.sk[t]; ++z) g += u.slab[(size_t)z * u.zstride + i];
-    const float w = u.W[t][j] - u.lr * g;
+    float w;
+    if (u.adam) {
+        float m = u.Wm[t][j], v = u.Wv[t][j];
+        w = adam_step(u.W[t][j], g, m, v, u.lr, u.beta1, u.beta2, u.eps);
+        u.Wm[t][j] = m; u.Wv[t][j] = v;
+    } else w = u.W[t][j] - u.lr * g;
     u.W[t][j] = w;
     const int r = (int)(j / u.Dout[t]), c = (int)(j % u.Dout[t]);
     static_cast<T*>(u.wf[t])[ft_off<T>(c, r, u.Din[t])] = (T)w;
@@ -302,6 +338,8 @@ struct ipnn_handle {
     ipnn_cfg cfg{}; std::string err; int dev = 0; hipStream_t st = nullptr; bool own_stream = false;
     int F = 0, K = 0, L = 0, P = 0, CB = 0, Bmax = 0, ldT = 0; bool bf16 = false; int splitk = 8;   // splitk: slab capacity
     std::vector<int> sk;                         // split-K of each layer's weight-gradient product
+    bool adam = false; int64_t adam_t = 0;       // Adam state: step count, moments of every tensor, dense row-gradient table
+    std::vector<float*> Wm, Wv; float *tm = nullptr, *tv = nullptr, *tG = nullptr, *bmv = nullptr;
     std::vector<int> d, Dp;                      // d[0..L+1], padded
     float* table16 = nullptr; int64_t n_rows = 0; float* b = nullptr;
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
@@ -436,10 +474,21 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     }
     {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
         IpProf ps(h, "scatter");
-        ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, (double)h->cfg.lr, h->table16, h->part, h->owner_cnt,
-                    h->owners, SLOT};
+        // Adam: the same sorted sums land in the (zero) gradient table instead: G[row] = 0 * 1 - (-1) * sum
+        ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, h->adam ? -1.0 : (double)h->cfg.lr,
+                    h->adam ? h->tG : h->table16, h->part, h->owner_cnt, h->owners, SLOT};
         hipLaunchKernelGGL(k_scat1, dim3(F * SORT_N / 256), dim3(256), 0, h->st, sa);
         hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, sa);
+    }
+    float lr_step = h->cfg.lr;
+    if (h->adam) {
+        h->adam_t += 1;
+        lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
+                          (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
+        IpProf ps(h, "adam_table");
+        const size_t n = (size_t)h->n_rows * SLOT;
+        hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, h->table16, h->tm, h->tv, h->tG, n,
+                           lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps);
     }
     {
         IpProf ps(h, "update");
@@ -450,7 +499,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             u.Din[t - 1] = h->Dp[t - 1]; u.Dout[t - 1] = h->Dp[t]; u.sk[t - 1] = h->sk[t - 1];
             off += (size_t)h->Dp[t - 1] * h->Dp[t];
         }
-        u.n = L + 1; u.off[L + 1] = off; u.slab = h->slab; u.zstride = h->slab_stride; u.lr = h->cfg.lr;
+        u.n = L + 1; u.off[L + 1] = off; u.slab = h->slab; u.zstride = h->slab_stride; u.lr = lr_step;
+        u.adam = h->adam ? 1 : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
+        if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
         hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off + 255) / 256 + 1)), dim3(256), 0, h->st, u);
     }
@@ -472,6 +523,8 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         cfg->max_batch < 1 || cfg->max_batch > 4096 || !(cfg->keep_prob > 0.f && cfg->keep_prob <= 1.f)) {
         g_ip_err = "bad shape (2..32 fields, k <= 16, 1..8 hidden layers, batch <= 4096, 0 < keep_prob <= 1)"; return FNN_ERR_ARG; }
     if (cfg->act != A_TANH && cfg->act != A_SIG && cfg->act != A_RELU) { g_ip_err = "bad act"; return FNN_ERR_ARG; }
+    if (cfg->optimizer != IPNN_OPT_SGD && cfg->optimizer != IPNN_OPT_ADAM) { g_ip_err = "bad optimizer"; return FNN_ERR_ARG; }
+    if (cfg->optimizer == IPNN_OPT_ADAM && !(cfg->adam_eps > 0.f)) { g_ip_err = "Adam needs adam_eps > 0"; return FNN_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_ip_err = "no HIP device (libfnn_hip.so has no CPU fallback)"; return FNN_ERR_HIP; }
     ipnn_handle* h = new ipnn_handle();
@@ -504,6 +557,15 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(al(&h->dl[t - 1], Ba * h->Dp[t] * tsz)); IK(al(&h->dlT[t - 1], Ba * h->Dp[t] * tsz));
     }
     for (int t = 0; t <= h->L; ++t) { IK(al(&h->a[t], Ba * h->Dp[t] * tsz)); IK(al(&h->aT[t], Ba * h->Dp[t] * tsz)); }
+    h->adam = cfg->optimizer == IPNN_OPT_ADAM;
+    if (h->adam) {
+        h->Wm.assign(h->L + 1, nullptr); h->Wv.assign(h->L + 1, nullptr);
+        for (int t = 1; t <= h->L + 1; ++t) {
+            const size_t n = (size_t)h->Dp[t - 1] * h->Dp[t];
+            IK(al((void**)&h->Wm[t - 1], n * 4)); IK(al((void**)&h->Wv[t - 1], n * 4));
+        }
+        IK(al((void**)&h->bmv, 8));
+    }
     h->maskT.assign(h->L + 1, nullptr);
     for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT[t], Ba * h->Dp[t]));
     h->slab_stride = nw;
@@ -539,6 +601,9 @@ int ipnn_destroy(ipnn_handle* h)
     for (auto v : {&h->wf, &h->wb, &h->a, &h->aT, &h->dl, &h->dlT}) for (void* p : *v) if (p) hipFree(p);
     for (float* p : h->W) if (p) hipFree(p);
     for (uint8_t* p : h->maskT) if (p) hipFree(p);
+    for (float* p : h->Wm) if (p) hipFree(p);
+    for (float* p : h->Wv) if (p) hipFree(p);
+    for (float* p : {h->tm, h->tv, h->tG, h->bmv}) if (p) hipFree(p);
     void* ptrs[] = {h->table16, h->b, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
                     h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -574,6 +639,14 @@ int ipnn_set_table(ipnn_handle* h, const float* rows, int64_t n_rows)
     hipFree(tmp);
     h->n_rows = n_rows;
     h->key64 = (unsigned long long)n_rows * SORT_N > 0xFFFFFFFFull;
+    if (h->adam) {                                              // fresh moments and gradient table for the new rows
+        for (float** p : {&h->tm, &h->tv, &h->tG}) {
+            if (*p) { hipFree(*p); *p = nullptr; }
+            IHK(h, hipMalloc((void**)p, n * 4));
+            IHK(h, hipMemset(*p, 0, n * 4));
+        }
+        h->adam_t = 0;
+    }
     return FNN_OK;
 }
 

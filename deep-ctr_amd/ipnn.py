@@ -3,7 +3,7 @@
 `IPNNEngine` is the PyTorch-ROCm plumbing; the three class names of the reference are kept as
 constructors with its `_rch_argv` layout (X_dim, X_feas, rank, h1..hN, act_func), its `forward`
 role (`train_step` / `predict`) and its `dump` keys (`W`, `V`, `b`, `h{i}_w`, `h{i}_b`).
-Categorical fields only; plain SGD (Adam of python/baseline.py:146 is not built)."""
+Categorical fields only; optimiser 'sgd' or 'adam' (python/tf_util.py:15-29; FTRL is not built)."""
 import ctypes as C
 import pickle
 
@@ -15,7 +15,7 @@ from .engine import FNNError
 
 class IPNNEngine(object):
     def __init__(self, n_fields, k, hidden, act='relu', max_batch=4096, precision='bf16', lr=1e-4, keep_prob=0.5, device=0,
-                 pairs=True):
+                 pairs=True, optimizer='sgd', adam_eps=1e-8, adam_betas=(0.9, 0.999)):
         import torch
         if not torch.cuda.is_available():
             raise FNNError(_capi.FNN_ERR_HIP, "no HIP device visible to PyTorch-ROCm; no CPU fallback")
@@ -26,7 +26,8 @@ class IPNNEngine(object):
         self.d = [n_fields * k + (n_fields * (n_fields - 1) // 2 if pairs else 0) + 1] + self.hidden + [1]
         hid = (C.c_int32 * 8)(*(self.hidden + [0] * (8 - len(self.hidden))))
         cfg = _capi.ipnn_cfg(n_fields, k, len(self.hidden), hid, _capi.IPNN_ACTS[act], 1 if pairs else 0, max_batch,
-                             1 if precision == 'bf16' else 0, lr, keep_prob, device, C.c_void_p(self.stream.cuda_stream))
+                             1 if precision == 'bf16' else 0, lr, keep_prob, {'sgd': 0, 'adam': 1}[optimizer], adam_betas[0],
+                             adam_betas[1], adam_eps, device, C.c_void_p(self.stream.cuda_stream))
         h = C.c_void_p()
         rc = self.lib.ipnn_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -136,11 +137,12 @@ class _IPFamily(object):
         X_dim, X_feas, rank = _rch_argv[:3]
         hidden, act = list(_rch_argv[3:-1]), _rch_argv[-1]
         assert len(hidden) == self.N_HIDDEN
-        if _ptmzr_argv[0] != 'sgd':
-            raise NotImplementedError("only plain SGD is built (the reference's Adam/FTRL: python/tf_util.py:15-29)")
+        if _ptmzr_argv[0] not in ('sgd', 'adam'):                    # python/tf_util.py:15-29
+            raise NotImplementedError("optimizer %r: sgd and adam are built (the reference's FTRL is not)" % (_ptmzr_argv[0],))
         self.keep = _reg_argv[0] if mode == 'train' else 1.0
         self.eng = IPNNEngine(X_feas, rank + 1, hidden, act, max_batch=max(batch_size, eval_size, 1), precision=precision,
-                              lr=_ptmzr_argv[1], keep_prob=self.keep, pairs=self.PAIRS)
+                              lr=_ptmzr_argv[1], keep_prob=self.keep, pairs=self.PAIRS, optimizer=_ptmzr_argv[0],
+                              adam_eps=_ptmzr_argv[2] if _ptmzr_argv[0] == 'adam' else 1e-8)
         lo, hi, seeds, path = _init_argv[1], _init_argv[2], _init_argv[3], _init_argv[-1]
         var_map = pickle.load(open(path, 'rb')) if path else {}
         d = self.eng.d

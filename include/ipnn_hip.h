@@ -4,8 +4,7 @@
  * pattern): `forward` :102-133 (embeddings, pair-wise inner products, z1 = [e | p | b], then
  * l_{t+1} = dropout(act(l_t)) W_t + b_t with activation and inverted dropout BEFORE every matmul),
  * the loss sum(sigmoid_cross_entropy_with_logits) :82-88 and the gradient step.  Categorical
- * fields only (iPinYou shape: one id per field); optimiser: plain SGD (the reference's Adam,
- * python/baseline.py:146, is not built).  Dropout keep-masks are INPUTS (uint8, one per element,
+ * fields only (iPinYou shape: one id per field); optimiser: plain SGD or Adam (IPNN_OPT_*).  Dropout keep-masks are INPUTS (uint8, one per element,
  * reference column order), NULL = no dropout (`drop_out=False`).
  *
  * Error codes are the FNN_ERR_* of fnn_hip.h; ipnn_last_error() has the message.
@@ -25,6 +24,12 @@ extern "C" {
 
 #define IPNN_MAX_HIDDEN  8
 
+#define IPNN_OPT_SGD     0      /* python/tf_util.py:26-29 GradientDescentOptimizer                       */
+#define IPNN_OPT_ADAM    1      /* python/tf_util.py:17-20 AdamOptimizer(learning_rate, epsilon): the
+                                   reference's choice for this family (python/baseline.py:146, lr 1e-4,
+                                   eps 1e-8).  TensorFlow's gradient of the embedding tables is dense, so
+                                   EVERY row's moments decay and every row moves each step             */
+
 typedef struct ipnn_cfg {
     int32_t n_fields;                  /* X_feas                                             */
     int32_t k;                         /* rank + 1: embedding row [w | v]  (FNN_IP_L7.py:66) */
@@ -37,6 +42,9 @@ typedef struct ipnn_cfg {
     int32_t precision;                 /* FNN_PREC_F32 / FNN_PREC_BF16                       */
     float   lr;
     float   keep_prob;                 /* _reg_argv[0]                                       */
+    int32_t optimizer;                 /* IPNN_OPT_*                                         */
+    float   adam_beta1, adam_beta2;    /* TensorFlow defaults 0.9, 0.999                     */
+    float   adam_eps;                  /* _ptmzr_argv[2]                                     */
     int32_t device;
     void*   stream;
 } ipnn_cfg;

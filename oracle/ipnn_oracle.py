@@ -101,6 +101,38 @@ def sgd_step(params, table, ids, y, act_name, lr, masks=None, keep=1.0):
     return loss, logits, g
 
 
+def adam_state(params, table):
+    z = lambda a: np.zeros_like(np.asarray(a, dtype=np.float64))        # noqa: E731
+    return {'t': 0, 'W': [(z(w), z(w)) for w in params['W']], 'bias': [(z(b), z(b)) for b in params['bias']],
+            'b': [0.0, 0.0], 'table': (z(table), z(table))}
+
+
+def adam_step(params, table, ids, y, act_name, lr, st, masks=None, keep=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One step of TensorFlow's AdamOptimizer (python/tf_util.py:17-20; python/baseline.py:146) on EVERY
+    variable: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); m <- beta1 m + (1 - beta1) g; v <- beta2 v +
+    (1 - beta2) g^2; theta <- theta - lr_t m / (sqrt(v) + eps).  The table's gradient is dense (zero rows
+    for untouched features), so all of its moments decay and all rows move.  Mutates params, table, st."""
+    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep)
+    st['t'] += 1
+    lr_t = lr * np.sqrt(1 - beta2 ** st['t']) / (1 - beta1 ** st['t'])
+
+    def upd(theta, grad, mv):
+        m, v = mv
+        m[...] = beta1 * m + (1 - beta1) * grad
+        v[...] = beta2 * v + (1 - beta2) * grad * grad
+        return theta - lr_t * m / (np.sqrt(v) + eps)
+    for t in range(len(params['W'])):
+        params['W'][t] = upd(params['W'][t], g['W'][t], st['W'][t])
+        params['bias'][t] = upd(params['bias'][t], g['bias'][t], st['bias'][t])
+    mb = [np.array(st['b'][0]), np.array(st['b'][1])]
+    params['b'] = float(upd(np.array(params['b']), np.array(g['b']), mb))
+    st['b'] = [float(mb[0]), float(mb[1])]
+    gt = np.zeros_like(table)
+    np.add.at(gt, ids, g['e'])
+    table[...] = upd(table, gt, st['table'])
+    return loss, logits, g
+
+
 def predict(params, table, ids, act_name):
     logits, _ = forward(params, table, ids, act_name)
     return 1.0 / (1.0 + np.exp(-logits))

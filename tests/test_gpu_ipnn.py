@@ -114,3 +114,29 @@ def test_plain_fnn_class_without_pair_products(built, tmp_path):
     m.dump(str(tmp_path / 'fnn.pickle'))
     vm = pickle.load(open(tmp_path / 'fnn.pickle', 'rb'))
     assert set(vm) == {'W', 'V', 'b', 'h1_w', 'h1_b', 'h2_w', 'h2_b', 'h3_w', 'h3_b'} and vm['h1_w'].shape == (F * K + 1, 48)
+
+
+def test_adam_steps_vs_oracle(built):
+    """Adam as TensorFlow applies it to this family (python/baseline.py:146): three steps, dense moment
+    decay of the whole table included (rows no batch touched move too), against oracle.adam_step."""
+    table, ids, y, params, masks, d = problem(160, [40, 24, 12], seed=21)
+    eng = IPNNEngine(F, K, [40, 24, 12], 'relu', max_batch=256, precision='f32', lr=1e-3, keep_prob=0.7, optimizer='adam',
+                     adam_eps=1e-8)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    st = io.adam_state(params, table)
+    t0, W0 = table.copy(), [w.copy() for w in params['W']]
+    m64 = [m.astype(np.float64) for m in masks]
+    for step in range(3):
+        out = eng.train_step(ids, y, masks, want_logits=True)
+        loss, logits, _ = io.adam_step(params, table, ids, y, 'relu', 1e-3, st, m64, 0.7)
+        np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=5e-4, atol=5e-5)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - W0[t]).max()
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 5e-3 * cw + 1e-7, t
+    rows = eng.get_rows(np.arange(table.shape[0]))
+    ct = np.abs(table - t0).max()
+    assert np.abs(rows - table).max() <= 5e-3 * ct + 1e-7
+    untouched = np.setdiff1d(np.arange(table.shape[0]), np.unique(ids))
+    assert len(untouched) > 0 and np.array_equal(rows[untouched], t0[untouched].astype(np.float32))     # zero gradient, zero moments: no move
+    eng.close()

@@ -253,3 +253,18 @@ def test_rbm_line_dicts_follow_the_reference_orders(tmp_path):
     assert lines == [([10, 11, 20], [1, 1, 1]), ([11, 10, 30], [1, 1, 0])]
     act = gbrbm.dense_active_ids(lines, 4)
     assert sorted(a for a in act[0] if a >= 0) == [11, 20] and sorted(a for a in act[1] if a >= 0) == [10, 11]
+
+
+def test_baseline_early_stop_and_recalibration():
+    """deep-ctr_amd/baseline.py against python/baseline.py:262-281 and :368-369 worked by hand."""
+    from deep_ctr_amd import baseline as bl
+    p = np.array([0.5, 0.1, 0.9])
+    np.testing.assert_allclose(bl.re_calibrate(p, 0.025), p / (p + (1 - p) / 0.025))
+    assert abs(bl.re_calibrate([0.5], 0.025)[0] - 0.025 / 1.025) < 1e-15
+    bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = 2, 1, 2, 2
+    assert not bl.early_stop(2, [0.6, 0.7, 0.8])                 # not after least_step yet
+    assert not bl.early_stop(3, [0.6, 0.7, 0.8, 0.9])            # smoothed auc still rising
+    assert bl.early_stop(5, [0.6, 0.7, 0.8, 0.7, 0.6])           # smoothed auc falls: (0.65) - (0.75) < 0
+    assert bl.early_stop(5, [0.3, 0.2, 0.2, 0.3, 0.4], metric='rmse')
+    assert not bl.early_stop(5, [0.9], metric='auc')             # too few smoothed points
+    bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = 0, 1, 1, 2
