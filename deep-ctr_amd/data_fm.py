@@ -127,3 +127,17 @@ class DataFM(object):
     def table(self):
         """(rows float32 [D,K], field_of_row int32 [D], w_0) for FNNEngine.set_table."""
         return self.rows.astype(numpy.float32), self.field_of_row, self.w_0
+
+    def write_fm_model(self, path, rows=None):
+        """Checkpoint the FM rows in the `fm.model.txt` text format (python/FNN_wnzh.py:68-84 reads it;
+        the reference never saves the rows its sparse update changes).  `rows` [D, K]: default = the
+        attached engine's current table (fnn_get_table), else the parse-time rows.  repr() keeps the
+        float32 values exact, so DataFM(path) reproduces them bit for bit."""
+        if rows is None:
+            rows = self.engine.get_table() if self.engine is not None else self.rows
+        names = sorted(self.name_field, key=self.name_field.get)
+        with open(path, 'w') as f:
+            f.write('%r %d %d\n' % (float(self.w_0), len(rows), self.k - 1))
+            for i in range(len(rows)):
+                f.write('%d %s %s:%d\n' % (self.feat_ids[i], ' '.join(repr(float(v)) for v in rows[i]),
+                                           names[int(self.field_of_row[i])], self.feat_ids[i]))

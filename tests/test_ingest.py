@@ -161,3 +161,14 @@ def test_large_file_thread_counts_agree(built, tmp_path):
     # the per-batch reference API reads the same lines (linecache, 1-based, blank lines skipped)
     f_arr, bid, by = d.get_batch_ids(str(tmp_path / 'train.fm.txt'), 1, 50)
     assert np.array_equal(bid, rid[:len(by)]) and np.array_equal(by, ry[:len(by)])
+
+
+def test_fm_model_checkpoint_round_trip(built, golden_dir, tmp_path):
+    """DataFM.write_fm_model -> DataFM: same ids, fields, w_0 and (float32) rows, bit for bit."""
+    d = DataFM(os.path.join(golden_dir, 'demo', 'fm.model.txt'))
+    rows = (d.rows * 1.5 + 0.25).astype(np.float32)              # stand-in for rows the sparse update changed
+    path = str(tmp_path / 'ckpt.fm.model.txt')
+    d.write_fm_model(path, rows)
+    e = DataFM(path)
+    assert e.w_0 == d.w_0 and e.k == d.k and np.array_equal(e.feat_ids, d.feat_ids) and np.array_equal(e.field_of_row, d.field_of_row)
+    assert np.array_equal(e.rows.astype(np.float32), rows)
