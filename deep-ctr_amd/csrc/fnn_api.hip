@@ -456,7 +456,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->bag = cfg->mode == FNN_MODE_BAG;
     if (h->bag) { h->rw = cfg->h0; h->K = cfg->h0; h->xdim = cfg->h0; h->K1p = rup(cfg->h0 + 1, 64); }
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
-    h->N2max = 256; while (h->N2max < h->Bmax) h->N2max <<= 1;
+    h->N2max = SORT_N; while (h->N2max < h->Bmax) h->N2max <<= 1;    // the three-launch path groups SORT_N slots per field whatever max_batch is
     h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
     h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
     h->bf16 = cfg->precision == FNN_PREC_BF16;

@@ -541,7 +541,6 @@ def make_snn_problem(B, n_rows=600, h0=200, seed=0, dup_col=None, empty=()):
     for (t, f) in empty:
         ids[t, f] = -1
     y = (rng.uniform(size=B) < 0.3).astype(np.float32)
-    dl = __import__('deep_ctr_amd').dl_utils
     p = {'w1': f32r(rng.uniform(-0.3, 0.3, (h0, H1))), 'b1': f32r(rng.uniform(-0.1, 0.1, H1)),
          'w2': f32r(rng.uniform(-0.3, 0.3, (H1, H2))), 'b2': f32r(rng.uniform(-0.1, 0.1, H2)),
          'w3': f32r(rng.uniform(-0.2, 0.2, H2)), 'b3': 0.05}
@@ -680,4 +679,14 @@ def test_train_step_with_64bit_sort_keys(built):
     change = np.abs(rows64[touched] - rows[touched]).max()
     assert np.abs(eng.get_rows(touched) - rows64[touched]).max() <= 2e-3 * change + 2e-7      # two f32 steps
     assert eng.lib.fnn_sync(eng.h) == 0
+    eng.close()
+
+
+def test_small_max_batch_handle(built):
+    """A handle created for a small max_batch (as __graft_entry__.smoke does) still groups 4096 slots
+    per field in the three-launch path: its grouping buffers must be sized for that, not for max_batch
+    (an out-of-bounds write here once faulted the GPU)."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(100, seed=5, dup_col=2)
+    eng = make_engine(rows, fo, p, max_batch=128, lr=0.01, lam1=0.0, lamfm=0.1)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.0, 0.1)
     eng.close()
