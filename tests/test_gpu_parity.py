@@ -690,3 +690,28 @@ def test_small_max_batch_handle(built):
     eng = make_engine(rows, fo, p, max_batch=128, lr=0.01, lam1=0.0, lamfm=0.1)
     _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.0, 0.1)
     eng.close()
+
+
+@pytest.mark.parametrize("B,max_batch", [(5000, 8192), (9000, 16384)])
+def test_train_step_above_4096_examples(built, B, max_batch):
+    """B > 4096 leaves the three-launch path for the layer-by-layer kernels and the per-field LDS sort
+    of 8,192 / 16,384 keys (k_sort<8> / <16>): one step against the oracle (vectorised A6, itself
+    checked against the sequential loop in tests/test_oracle.py)."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(B, n_rows=3000, seed=B, dup_col=6)
+    eng = make_engine(rows, fo, p, max_batch=max_batch, lr=0.001, lam1=0.0, lamfm=0.1)
+    out = eng.train_step(ids, y, r1, r2, want_p=True)
+    rows64 = rows.astype(np.float64).copy()
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    x = orc.gather(rows64, ids, -3.0)
+    gx, _, loss, p_drop, g = orc.train_call(p64, x, y.astype(np.float64), r1.astype(np.float64), r2.astype(np.float64), 0.001, 0.0)
+    orc.scatter_sgd_vec(rows64, ids, gx, 0.001, 0.1)
+    np.testing.assert_allclose(out['p'].cpu().numpy(), p_drop, rtol=1e-4, atol=1e-6)
+    assert abs(out['loss'] - loss) <= 5e-5 * abs(loss)
+    touched = np.unique(ids)
+    change = np.abs(rows64[touched] - rows[touched]).max()
+    assert np.abs(eng.get_rows(touched) - rows64[touched]).max() <= 2e-3 * change + 2e-7
+    d = eng.get_dense()
+    for k in ('w1', 'w2', 'w3'):
+        gs = 0.001 * np.abs(g[k]).max()
+        np.testing.assert_allclose(d[k], p64[k], rtol=1e-5, atol=2e-3 * gs + 1e-7, err_msg=k)
+    eng.close()
