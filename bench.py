@@ -55,10 +55,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather'],
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm'],
                     help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
                          'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
-                         'gather: the standalone embedding gathers (A3: FM rows; A8: 200-wide bag rows) against the HBM roofline')
+                         'gather: the standalone embedding gathers (A3: FM rows; A8: 200-wide bag rows) against the HBM roofline.  '
+                         'rbm: SNN pre-training of configs[4] -- the exact online sparse CD-1 pass and a dense CD-1 layer')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -66,6 +67,8 @@ def main():
         return bench_ipnn(args)
     if args.workload == 'gather':
         return bench_gather(args)
+    if args.workload == 'rbm':
+        return bench_rbm(args)
 
     import torch
     import deep_ctr_amd  # noqa: F401
@@ -237,6 +240,75 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_rbm(args):
+    """SNN pre-training (BASELINE configs[4]; python/sampling_based_gaussian_binary_rbm_sparse.py) at the
+    config shape: the sparse first layer 937,670 x 200 (750 MB), 32 sampled visibles per example, in the
+    reference's EXACT online mode (one example at a time, sequential by definition: one workgroup), and
+    the dense 200 -> 300 CD-1 layer on mini-batches of 4096 (MFMA kernels).  A 'step' = 4096 examples."""
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import _capi, synth
+    lib = _capi.load()
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    N, H0, H1, S = 4096, 200, 300, 32
+    sizes = synth.field_sizes_ipinyou()
+    D = sum(sizes)
+    rng = np.random.default_rng(3)
+    ids = np.sort(2 * synth.zipf_ids(N, sizes, 1.1, 5).astype(np.int64) % (D - 2) + 1, axis=1)     # 16 odd ids: id - 1 never collides
+    vid = np.empty((N, S), np.int32); vid[:, 0::2] = ids - 1; vid[:, 1::2] = ids
+    vid.sort(axis=1)
+    vval = np.isin(vid, ids).astype(np.uint8) if False else ((vid % 2) == 1).astype(np.uint8)
+    W = torch.as_tensor(rng.uniform(-0.1, 0.1, (D, H0)).astype(np.float32)).to(dev)
+    vb = torch.zeros(D, dtype=torch.float32, device=dev); hb = torch.zeros(H0, dtype=torch.float32, device=dev)
+    ws = torch.zeros((S, H0), dtype=torch.float32, device=dev)
+    vid_d, vval_d = torch.as_tensor(vid).to(dev), torch.as_tensor(vval).to(dev)
+    unif = torch.rand((N, H0), device=dev)
+    err = C.c_double()
+
+    def sparse_pass():
+        rc = lib.rbm_sparse_epoch(W.data_ptr(), vb.data_ptr(), hb.data_ptr(), ws.data_ptr(), vid_d.data_ptr(), vval_d.data_ptr(),
+                                  unif.data_ptr(), N, H0, S, 2e-4, 1e-4, 1e-4, 1e-4, 0.9, C.byref(err), st)
+        if rc != 0:
+            raise RuntimeError(lib.rbm_last_error().decode())
+    for _ in range(max(1, args.warmup // 10)):
+        sparse_pass()
+    torch.cuda.synchronize(dev)
+    n_sp = max(2, args.steps // 20)
+    t0 = time.perf_counter()
+    for _ in range(n_sp):
+        sparse_pass()
+    torch.cuda.synchronize(dev)
+    dt_sp = (time.perf_counter() - t0) / n_sp
+    # dense CD-1 layer 200 -> 300
+    h = C.c_void_p()
+    if lib.rbm_dense_create(H0, H1, N, 1 if args.precision == 'bf16' else 0, 0, st, C.byref(h)) != 0:
+        raise RuntimeError(lib.rbm_last_error().decode())
+    Wd = rng.uniform(-0.1, 0.1, (H0, H1)).astype(np.float32); v0 = np.zeros(H0, np.float32); h0 = np.zeros(H1, np.float32)
+    lib.rbm_dense_set(h, Wd.ctypes.data, v0.ctypes.data, h0.ctypes.data)
+    X = torch.rand((N, H0), device=dev); U = torch.rand((N, H1), device=dev)
+    for _ in range(args.warmup):
+        lib.rbm_dense_cd1(h, X.data_ptr(), N, U.data_ptr(), 2e-4, 1e-4, 1e-4, 1e-4, 0.9, None)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lib.rbm_dense_cd1(h, X.data_ptr(), N, U.data_ptr(), 2e-4, 1e-4, 1e-4, 1e-4, 0.9, None)
+    torch.cuda.synchronize(dev)
+    dt_de = (time.perf_counter() - t0) / args.steps
+    lib.rbm_dense_destroy(h)
+    per_ex = S * H0 * 4 * 2 + S * 8 + H0 * 4                   # 32 rows read + written, ids/values, uniforms
+    print(json.dumps({
+        'metric': 'examples/sec', 'value': N / dt_sp, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': n_sp, 'warmup': args.warmup,
+        'ms_per_step': dt_sp * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SNN pre-training, sparse RBM layer 937670 x 200, 32 sampled visibles per example, EXACT online CD-1 '
+                               '(batch 1, sequential: one workgroup); a step = %d examples' % N},
+        'roofline': {'kernel': 'k_rbm_sparse', 'bound': 'hbm', 'achieved': per_ex * N / dt_sp / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': per_ex * N / dt_sp / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_per_example': per_ex,
+                     'note': 'latency-bound by construction: example n reads the rows example n-1 wrote'},
+        'dense_cd1_200x300': {'examples_per_sec': N / dt_de, 'ms_per_minibatch_of_4096': dt_de * 1e3, 'dtype': args.precision},
+        'cpu_baseline': None}))
 
 
 def bench_gather(args):
