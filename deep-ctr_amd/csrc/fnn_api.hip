@@ -250,7 +250,7 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
     }
     {
         ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
-        const int nred = dense ? (int)((h->nw + h->nbag + 255) / 256) + 1 : 0;
+        const int nred = dense ? (int)((h->nw12 / 4 + 255) / 256) + (int)((h->nw - h->nw12 + h->nbag + 255) / 256) + 1 : 0;
         TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
                     h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
                     h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};

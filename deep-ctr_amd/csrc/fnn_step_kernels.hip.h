@@ -222,7 +222,41 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
         if (threadIdx.x == 0) *ta.loss_sum = s_l[0];
         return;
     }
-    const size_t i = (size_t)b * 256 + threadIdx.x;
+    // Dense tensors W1p, W2p: 4 consecutive elements per thread (same row, 4 columns: 16-byte slab / master
+    // accesses, one 8-byte piece of the [in][out] shadow); the short tail (w3p, bag bias) one element each.
+    const size_t nvec = ta.nw12 / 4;
+    const int nvb = (int)((nvec + 255) / 256);
+    if (b < nvb) {
+        const size_t q = (size_t)b * 256 + threadIdx.x;
+        if (q >= nvec) return;
+        const size_t i = q * 4;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = 0; z < ta.splitk; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(ta.slab + (size_t)z * ta.nslab + i);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+        *reinterpret_cast<float4*>(ta.bucket + i) = g;          // data term only (what data parallelism all-reduces)
+        if (UPDATE) {
+            float4 w = *reinterpret_cast<const float4*>(ta.master + i);
+            const float l2 = ta.reg_all ? 2.0f * ta.lambda1 : 0.0f;     // L2 term (:173; only w3, b3 unless reg_all)
+            w.x -= ta.lr * (g.x + l2 * w.x); w.y -= ta.lr * (g.y + l2 * w.y);
+            w.z -= ta.lr * (g.z + l2 * w.z); w.w -= ta.lr * (g.w + l2 * w.w);
+            *reinterpret_cast<float4*>(ta.master + i) = w;
+            const size_t n1 = (size_t)ta.K1p * ta.H1p;
+            const bool first = i < n1;
+            const size_t j = first ? i : i - n1;
+            const int ld = first ? ta.H1p : ta.H2p, kin = first ? ta.K1p : ta.H1p;
+            const int r = (int)(j / ld), c = (int)(j % ld);
+            T* wn = static_cast<T*>(first ? ta.w1 : ta.w2);     // [in][out]: k = column, 4 consecutive
+            T* wt = static_cast<T*>(first ? ta.w1t : ta.w2t);   // [out][in]: k = row
+            store4(wn + ft_off<T>(r, c, ld), w.x, w.y, w.z, w.w);
+            wt[ft_off<T>(c, r, kin)] = (T)w.x; wt[ft_off<T>(c + 1, r, kin)] = (T)w.y;
+            wt[ft_off<T>(c + 2, r, kin)] = (T)w.z; wt[ft_off<T>(c + 3, r, kin)] = (T)w.w;
+        }
+        return;
+    }
+    const size_t i = ta.nw12 + (size_t)(b - nvb) * 256 + threadIdx.x;
     if (i >= ta.nw_all + ta.nbag) return;
     if (i >= ta.nw_all) {               // bag bias: bb0 -= lr * sum_t delta_t  (python/SNN_RBM.py:289)
         const size_t c = i - ta.nw_all;
@@ -233,27 +267,15 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
         if (UPDATE) ta.bb0[c] -= ta.lr * g;
         return;
     }
-    const size_t src = (i < ta.nw12) ? i : ta.nw12 + (i - ta.nw12) * 64;
+    const size_t src = ta.nw12 + (i - ta.nw12) * 64;            // w3p: column 0 of an [H2p][64] tile
     float g = 0.f;
 #pragma unroll 8
     for (int z = 0; z < ta.splitk; ++z) g += ta.slab[(size_t)z * ta.nslab + src];
     float w = ta.master[i];
-    ta.bucket[i] = g;                 // data term only (what data parallelism all-reduces)
+    ta.bucket[i] = g;
     if (UPDATE) {
-        if (ta.reg_all || i >= ta.nw12) g += 2.0f * ta.lambda1 * w;     // L2 term (:173)
-        w -= ta.lr * g;
-        ta.master[i] = w;
-        const size_t n1 = (size_t)ta.K1p * ta.H1p, n2 = (size_t)ta.H1p * ta.H2p;
-        if (i < n1) {
-            const int r = (int)(i / ta.H1p), c = (int)(i % ta.H1p);
-            static_cast<T*>(ta.w1t)[ft_off<T>(c, r, ta.K1p)] = (T)w;
-            static_cast<T*>(ta.w1)[ft_off<T>(r, c, ta.H1p)] = (T)w;
-        } else if (i < n1 + n2) {
-            const size_t j = i - n1;
-            const int r = (int)(j / ta.H2p), c = (int)(j % ta.H2p);
-            static_cast<T*>(ta.w2t)[ft_off<T>(c, r, ta.H1p)] = (T)w;
-            static_cast<T*>(ta.w2)[ft_off<T>(r, c, ta.H2p)] = (T)w;
-        }
+        g += 2.0f * ta.lambda1 * w;                              // w3, b3 are always regularised (:173)
+        ta.master[i] = w - ta.lr * g;
     }
 }
 
