@@ -293,6 +293,57 @@ static __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, in
     for (int n = 0; n < NT; ++n) epi(r0, (ct0 + n) * 16 + (lane & 15), acc[n], 0);
 }
 
+// Epilogue of a wave's TM x TN accumulator fragments (shared by k_gemm_ft and k_gemm_lds); `smem`: LDS of
+// gemm_ft_lds<T, TN>() bytes for a tile epilogue (unused otherwise).
+template <typename T, int TM, int TN, typename Epi>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const int rt0, const int ct0, const int wave, const int lane,
+                                              unsigned char* gemm_smem, const Epi& epi, const int z)
+{
+    const int rq = 4 * (lane >> 4), cl = lane & 15;              // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    if constexpr (Epi::TILE) {
+        // Activation-like output in both fragment-tiled orientations.  xT (rows = columns of C,
+        // k = rows of C): the lane's 4 accumulator rows are 4 consecutive k -> one 8-byte store.
+        // xF (rows = rows of C, k = columns): 16 rows at a time go through a wave-private LDS tile and
+        // leave as whole 1-KiB fragments (16 B per lane, fully coalesced) instead of 2-byte stores.
+        typedef typename Traits<T>::frag frag_t;
+        constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, LDP = 16 * TN + 8, KT = 16 * TN / KS;
+        T* tile = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * 16 * LDP;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                float v[4];
+                const int r0 = (rt0 + m) * 16 + rq, col = (ct0 + n) * 16 + cl;
+                epi.pre(r0, col, acc[m][n], v);
+                if (epi.outT) store4(epi.outT + ft_off<T>(col, r0, epi.ldT), v[0], v[1], v[2], v[3]);
+                if (epi.outF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile[(rq + r) * LDP + n * 16 + cl] = (T)v[r];
+                }
+            }
+            if (epi.outF) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) {
+                    const frag_t f = *reinterpret_cast<const frag_t*>(tile + (lane & 15) * LDP + kk * KS + (lane >> 4) * EPL);
+                    T* dst = epi.outF + ((size_t)((rt0 + m) * (epi.ld / KS) + (ct0 * 16) / KS + kk) * 64 + lane) * EPL;
+                    *reinterpret_cast<frag_t*>(dst) = f;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) epi((rt0 + m) * 16 + rq, (ct0 + n) * 16 + cl, acc[m][n], z);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM on two FRAGMENT-TILED operands:  C[M][N] = sum_k A[M][k] * B[N][k], both stored with
 // ft_off (16 rows x KS k-values = one contiguous 1-KiB fragment in lane order), so every operand
@@ -345,54 +396,146 @@ static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A,
         load(a1, b1, kt + 4);
         mul(a2, b2);
     }
-    const int rq = 4 * (lane >> 4), cl = lane & 15;              // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
-    if constexpr (Epi::TILE) {
-        // Activation-like output in both fragment-tiled orientations.  xT (rows = columns of C,
-        // k = rows of C): the lane's 4 accumulator rows are 4 consecutive k -> one 8-byte store.
-        // xF (rows = rows of C, k = columns): 16 rows at a time go through a wave-private LDS tile and
-        // leave as whole 1-KiB fragments (16 B per lane, fully coalesced) instead of 2-byte stores.
-        typedef typename Traits<T>::frag frag_t;
-        constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, LDP = 16 * TN + 8, KT = 16 * TN / KS;
-        extern __shared__ __align__(16) unsigned char gemm_smem[];
-        T* tile = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * 16 * LDP;
-#pragma unroll
-        for (int m = 0; m < TM; ++m) {
-#pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                float v[4];
-                const int r0 = (rt0 + m) * 16 + rq, col = (ct0 + n) * 16 + cl;
-                epi.pre(r0, col, acc[m][n], v);
-                if (epi.outT) store4(epi.outT + ft_off<T>(col, r0, epi.ldT), v[0], v[1], v[2], v[3]);
-                if (epi.outF) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tile[(rq + r) * LDP + n * 16 + cl] = (T)v[r];
-                }
-            }
-            if (epi.outF) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int kk = 0; kk < KT; ++kk) {
-                    const frag_t f = *reinterpret_cast<const frag_t*>(tile + (lane & 15) * LDP + kk * KS + (lane >> 4) * EPL);
-                    T* dst = epi.outF + ((size_t)((rt0 + m) * (epi.ld / KS) + (ct0 * 16) / KS + kk) * 64 + lane) * EPL;
-                    *reinterpret_cast<frag_t*>(dst) = f;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n) epi((rt0 + m) * 16 + rq, (ct0 + n) * 16 + cl, acc[m][n], (int)blockIdx.z);
-    }
+    extern __shared__ __align__(16) unsigned char gemm_smem_ft[];
+    gemm_epilogue<T, TM, TN, Epi>(acc, rt0, ct0, wave, lane, gemm_smem_ft, epi, (int)blockIdx.z);
 }
 
 // dynamic LDS of k_gemm_ft for a tile epilogue: 4 wave-private [16][16 TN + 8] tiles
 template <typename T, int TN> constexpr size_t gemm_ft_lds() { return (size_t)4 * 16 * (16 * TN + 8) * sizeof(T); }
+
+// ------------------------------------------------------------------------------------------
+// The same product, operands staged through LDS: a workgroup (2 x 2 waves, 64 x 64 of C each) owns
+// 128 x 128 of C; one k-step of it is 8 + 8 fragments = 16 KiB, which the four waves fetch with four
+// global_load_lds_dwordx4 each (a fragment is 1 KiB contiguous in global memory AND lane-linear in
+// LDS, so the DMA needs no swizzle and ds_read_b128 of a fragment is conflict-free).  GEMM_NS k-steps
+// are in flight in a ring of LDS slots (one L2 round trip is ~6 k-steps of MFMA time and these
+// products are only 5-32 k-steps long, so the depth of the prefetch is what sets their speed); a
+// wave's next fragments are read from LDS into a second register set while the current ones
+// multiply.  One raw s_barrier per k-step with counted vmcnt waits (cdna_hip_programming.md
+// section 5, "Pipelining across barriers"): a slot is read only after the wait that retires its
+// loads AND a barrier, and re-filled only after a barrier that follows its last read.
+// grid = (ceil(M / 128), ceil(N / 128), splitK); M, N multiples of 64.
+// ------------------------------------------------------------------------------------------
+constexpr int GEMM_NS = 8;
+#ifdef GEMM_STAMPS                    // diagnostic builds only (tools/exp/gemm_bench.hip): per-workgroup phase time stamps
+__device__ long long* g_gemm_dbg;
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && g_gemm_dbg) g_gemm_dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_STAMP(i) do { } while (0)
+#endif
+template <typename T, bool TILE> constexpr size_t gemm_lds_bytes() {
+    return (size_t)GEMM_NS * 16 * 1024 + (TILE ? gemm_ft_lds<T, 4>() : 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    // gfx9 s_waitcnt: vmcnt = simm16[15:14] : simm16[3:0]; expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+}
+// wait until at most `groups` groups of 4 loads are outstanding (wave-uniform argument)
+__device__ __forceinline__ void wait_groups(const int groups) {
+    switch (groups) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<4>(); break;
+        case 2: wait_vmcnt<8>(); break;
+        case 3: wait_vmcnt<12>(); break;
+        case 4: wait_vmcnt<16>(); break;
+        case 5: wait_vmcnt<20>(); break;
+        default: wait_vmcnt<24>(); break;
+    }
+}
+
+template <typename T, typename Epi>
+static __global__ __launch_bounds__(256) void k_gemm_lds(const T* __restrict__ A, const T* __restrict__ Bm, int mt16, int nt16,
+                                                   int nkt_all, int nkt, Epi epi)
+{
+    typedef typename Traits<T>::frag frag;
+    constexpr int EPL = Traits<T>::EPL, NS = GEMM_NS;
+    static_assert(NS - 2 <= 6, "wait_groups covers up to 6 groups");
+    extern __shared__ __align__(16) unsigned char gemm_smem_l[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int rt0 = (blockIdx.x * 2 + wr) * 4, ct0 = (blockIdx.y * 2 + wc) * 4;
+    const int kt0 = blockIdx.z * nkt;
+    // the four fragments this wave stages per k-step: waves 0, 1 -> A row tiles, waves 2, 3 -> B column tiles
+    // (indices past the edge are clamped: they land in slots nobody multiplies)
+    const T* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = (wave & 1) * 4 + j;
+        const int tile = (wave < 2) ? min((int)blockIdx.x * 8 + f, mt16 - 1) : min((int)blockIdx.y * 8 + f, nt16 - 1);
+        src[j] = ft_frag<T>(wave < 2 ? A : Bm, tile, kt0, nkt_all, lane);
+    }
+    auto stage = [&](const int kt) {                       // k-step kt -> slot kt % NS
+        unsigned char* slot = gemm_smem_l + (size_t)(kt % NS) * 16384 + (size_t)wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)kt * 64 * EPL),
+                                             (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 0);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag a0[4], b0[4], a1[4], b1[4];
+    auto fetch = [&](frag* a, frag* b, const int kt) {     // this wave's fragments of k-step kt: LDS -> registers
+        const unsigned char* slot = gemm_smem_l + (size_t)(kt % NS) * 16384 + lane * 16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const frag*>(slot + (wr * 4 + m) * 1024);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const frag*>(slot + 8192 + (wc * 4 + n) * 1024);
+    };
+    auto mul = [&](const frag* a, const frag* b) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma(acc[m][n], a[m], b[n]);
+    };
+    GEMM_STAMP(0);
+    // prologue: k-steps 0 .. NS-2 in flight; k-step 0 landed, visible to all waves and in registers
+    const int npro = min(NS - 1, nkt);
+    for (int kt = 0; kt < npro; ++kt) stage(kt);
+    wait_groups(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    fetch(a0, b0, 0);
+    GEMM_STAMP(1);
+    // iteration kt: [wait k-step kt+1] [barrier: also, every wave has read slot kt] [refill the slot of kt-1... with
+    // k-step kt+NS-1] [read kt+1 into the other register set] [multiply kt]
+    auto iter = [&](const frag* ca, const frag* cb, frag* na, frag* nb, const int kt) {
+        if (kt + 1 < nkt) {
+            // issued so far: k-steps < min(kt + NS - 1, nkt); k-step kt + 1 must have landed
+            wait_groups(min(kt + NS - 1, nkt) - (kt + 2));
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's reads of slot kt are complete
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nkt) stage(kt + NS - 1);              // into the slot of k-step kt - 1 (read in iteration kt - 2)
+            fetch(na, nb, kt + 1);
+        }
+        mul(ca, cb);
+    };
+    // steady state (k-step kt + NS - 1 exists): no branches, fixed counts; in pairs for the register ping-pong
+    auto steady = [&](const frag* ca, const frag* cb, frag* na, frag* nb, const int kt) {
+        wait_vmcnt<4 * (NS - 3)>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        stage(kt + NS - 1);
+        fetch(na, nb, kt + 1);
+        mul(ca, cb);
+        __builtin_amdgcn_sched_barrier(0);                      // the products stay in front of the next step's wait
+    };
+    int kt = 0;
+    for (; kt + NS < nkt; kt += 2) {
+        steady(a0, b0, a1, b1, kt);
+        steady(a1, b1, a0, b0, kt + 1);
+    }
+    for (; kt < nkt; kt += 2) {
+        iter(a0, b0, a1, b1, kt);
+        if (kt + 1 < nkt) iter(a1, b1, a0, b0, kt + 1);
+    }
+    GEMM_STAMP(2);
+    if (rt0 < mt16 && ct0 < nt16)
+        gemm_epilogue<T, 4, 4, Epi>(acc, rt0, ct0, wave, lane, gemm_smem_l + (size_t)NS * 16384, epi, (int)blockIdx.z);
+    GEMM_STAMP(3);
+}
 
 // Weight gradients: gw = P^T Q with the contraction over the examples t (python/FNN_wnzh.py:174),
 // for the three products of a step in ONE launch: x'^T delta1, d1^T delta2, d2^T delta3.  Both

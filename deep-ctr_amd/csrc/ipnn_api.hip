@@ -351,6 +351,7 @@ struct ipnn_handle {
     double* cpow1 = nullptr; bool key64 = true;
     size_t slab_stride = 0;
     bool prof = false;                               // HIP-event timing of the step's segments
+    bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
 };
 
@@ -409,7 +410,16 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         const int mt16 = M / 16, nt16 = N / 16;
         const long wg44 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
         const size_t lds4 = E::TILE ? gemm_ft_lds<T, 4>() : 0, lds2 = E::TILE ? gemm_ft_lds<T, 2>() : 0;
-        if (wg44 >= 160)
+        if (wg44 >= 160 && h->gemm_lds) {
+            constexpr size_t ldsb = gemm_lds_bytes<T, E::TILE>();
+            static bool attr_set = false;                  // per instantiation (T, E): > 64 KiB of dynamic LDS needs the opt-in
+            if (!attr_set) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_lds<T, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_gemm_lds<T, E>), dim3((M + 127) / 128, (N + 127) / 128, splitk), dim3(256), ldsb, h->st, A, Bm,
+                               mt16, nt16, nkt_all, nkt, epi);
+        } else if (wg44 >= 160)
             hipLaunchKernelGGL((k_gemm_ft<T, 4, 4, E>), dim3((M + 127) / 128, (N + 127) / 128, splitk), dim3(256), lds4, h->st, A, Bm,
                                mt16, nt16, nkt_all, nkt, epi);
         else if (N > 64)
@@ -531,6 +541,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     h->cfg = *cfg; h->dev = cfg->device; h->F = cfg->n_fields; h->K = cfg->k; h->L = cfg->n_hidden;
     h->P = cfg->pairs ? h->F * (h->F - 1) / 2 : 0; h->CB = h->F * SLOT + h->P; h->bf16 = cfg->precision == FNN_PREC_BF16;
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
+    if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
     auto fail = [&](int code) { g_ip_err = h->err; ipnn_destroy(h); return code; };
 #define IK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e2_); return fail(FNN_ERR_HIP); } } while (0)
     IK(hipSetDevice(h->dev));
