@@ -355,14 +355,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const int rt
 // products per layer on it (forward, backward-data, weight gradient).
 // ------------------------------------------------------------------------------------------
 template <typename T, int TM, int TN, typename Epi>
-static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A, const T* __restrict__ Bm, int mt16, int nt16,
-                                                  int nkt_all, int nkt, Epi epi)
+__device__ __forceinline__ void gemm_ft_body(const T* __restrict__ A, const T* __restrict__ Bm, const int mt16, const int nt16,
+                                             const int nkt_all, const int nkt, const Epi& epi, const int bx, const int by, const int bz)
 {
     typedef typename Traits<T>::frag frag;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rt0 = (blockIdx.x * 2 + (wave & 1)) * TM, ct0 = (blockIdx.y * 2 + (wave >> 1)) * TN;
+    const int rt0 = (bx * 2 + (wave & 1)) * TM, ct0 = (by * 2 + (wave >> 1)) * TN;
     if (rt0 >= mt16 || ct0 >= nt16) return;
-    const int kt0 = blockIdx.z * nkt;
+    const int kt0 = bz * nkt;
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -397,7 +397,33 @@ static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A,
         mul(a2, b2);
     }
     extern __shared__ __align__(16) unsigned char gemm_smem_ft[];
-    gemm_epilogue<T, TM, TN, Epi>(acc, rt0, ct0, wave, lane, gemm_smem_ft, epi, (int)blockIdx.z);
+    gemm_epilogue<T, TM, TN, Epi>(acc, rt0, ct0, wave, lane, gemm_smem_ft, epi, bz);
+}
+
+template <typename T, int TM, int TN, typename Epi>
+static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A, const T* __restrict__ Bm, int mt16, int nt16,
+                                                  int nkt_all, int nkt, Epi epi)
+{
+    gemm_ft_body<T, TM, TN, Epi>(A, Bm, mt16, nt16, nkt_all, nkt, epi, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several independent products with plain f32 split-K output (the weight gradients of a whole stack) in ONE launch:
+// problem q owns workgroups wg0[q] .. wg0[q+1]-1, laid out (x fastest, then y, then the K split).
+constexpr int GEMM_GROUP_MAX = 9;
+struct GemmGroupProb { const void* A; const void* B; float* out; int mt16, nt16, nkt_all, nkt, ldo, gx, gy; };
+struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int wg0[GEMM_GROUP_MAX + 1]; int n; size_t zstride; };
+
+template <typename T, int TM, int TN>
+static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g)
+{
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_GROUP_MAX; ++i) q += (i < g.n && (int)blockIdx.x >= g.wg0[i]) ? 1 : 0;
+    const GemmGroupProb& pr = g.p[q];
+    const int local = (int)blockIdx.x - g.wg0[q];
+    const int bx = local % pr.gx, by = (local / pr.gx) % pr.gy, bz = local / (pr.gx * pr.gy);
+    const EpiF32 e{pr.out, pr.ldo, g.zstride};
+    gemm_ft_body<T, TM, TN, EpiF32>(static_cast<const T*>(pr.A), static_cast<const T*>(pr.B), pr.mt16, pr.nt16, pr.nkt_all, pr.nkt, e, bx, by, bz);
 }
 
 // dynamic LDS of k_gemm_ft for a tile epilogue: 4 wave-private [16][16 TN + 8] tiles

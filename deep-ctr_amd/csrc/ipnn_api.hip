@@ -7,6 +7,7 @@
 // own for the inner-product layer.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -32,6 +33,16 @@ __device__ inline float ip_act(float z, int act) {
     if (act == A_TANH) return tanhf(z);
     return 1.0f / (1.0f + expf(-z));
 }
+template <int ACT> __device__ inline float ip_act_c(float z) {
+    if (ACT == A_RELU) return fmaxf(z, 0.f);
+    if (ACT == A_TANH) return tanhf(z);
+    return 1.0f / (1.0f + expf(-z));
+}
+template <int ACT> __device__ inline float ip_dact_u_c(float u) {
+    if (ACT == A_RELU) return u > 0.f ? 1.0f : 0.0f;
+    if (ACT == A_TANH) return 1.0f - u * u;
+    return u * (1.0f - u);
+}
 // derivative of act at l, written in terms of u = act(l)
 __device__ inline float ip_dact_u(float u, int act) {
     if (act == A_RELU) return u > 0.f ? 1.0f : 0.0f;
@@ -53,47 +64,86 @@ struct IpFwdArgs {
     const uint8_t* mask; int d0; float inv_keep; int act; int D0p, ldT; int* err;
 };
 
-template <typename T>
-static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T)
+// gather of 16 examples' rows into an LDS tile [16][F*16]: all ids of a batch of 4 elements per thread first, then all
+// rows (two dependent round trips per batch instead of two per element)
+__device__ __forceinline__ void ip_gather16(float* se, const int32_t* __restrict__ ids, const float* __restrict__ table16,
+                                            const int64_t n_rows, const int t0, const int B, const int F, int* err)
 {
+    const int n = 16 * F * 4, FS = F * SLOT;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 4) {
+        int64_t id[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + 256 * j, f = (e >> 2) % F, t = t0 + (e >> 2) / F;
+            id[j] = (e < n && t < B) ? (int64_t)ids[(size_t)t * F + f] : -1;
+        }
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + 256 * j;
+            if (e < n && t0 + (e >> 2) / F < B && (id[j] < 0 || id[j] >= n_rows)) { if (err) atomicOr(err, 1); id[j] = -1; }
+            v[j] = id[j] >= 0 ? *reinterpret_cast<const float4*>(table16 + (size_t)id[j] * SLOT + 4 * (e & 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e0 + 256 * j;
+            if (e < n) *reinterpret_cast<float4*>(se + ((e >> 2) / F) * FS + ((e >> 2) % F) * SLOT + 4 * (e & 3)) = v[j];
+        }
+    }
+}
+
+template <typename T>
+static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T, float* __restrict__ emb)
+{
+    typedef typename Traits<T>::frag frag;
+    constexpr int EPL = Traits<T>::EPL;
     extern __shared__ __align__(16) unsigned char smem[];
     float* se = reinterpret_cast<float*>(smem);                 // [16][F*16] raw embeddings
     float* sa = se + 16 * a.F * SLOT;                           // [16][D0p]  a0 values
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
     const int P = a.P, CB = FS + P;
-    for (int e = tid; e < 16 * F * 4; e += 256) {               // gather: (example, field, quarter)
-        const int q = e & 3, f = (e >> 2) % F, r = (e >> 2) / F, t = t0 + r;
-        int64_t id = -1;
-        if (t < B) { id = a.ids[(size_t)t * F + f]; if (id < 0 || id >= a.n_rows) { atomicOr(a.err, 1); id = -1; } }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0) v = *reinterpret_cast<const float4*>(a.table16 + (size_t)id * SLOT + 4 * q);
-        *reinterpret_cast<float4*>(se + r * FS + f * SLOT + 4 * q) = v;
-    }
+    ip_gather16(se, a.ids, a.table16, a.n_rows, t0, B, F, a.err);
     __syncthreads();
+    if (emb)                                                    // kept for the backward of the inner products (no second gather)
+        for (int e = tid; e < 16 * FS / 4; e += 256)
+            *reinterpret_cast<float4*>(emb + (size_t)t0 * FS + 4 * e) = *reinterpret_cast<const float4*>(se + 4 * e);
     const float bval = *a.b;
-    for (int e = tid; e < 16 * a.D0p; e += 256) {
-        const int r = e / a.D0p, c = e % a.D0p, t = t0 + r;
-        float z = 0.f; int ref = -1;                            // ref: column in the reference's z1 order
-        if (c < FS) { const int f = c / SLOT, l = c % SLOT; if (l < K) { z = se[r * FS + c]; ref = f * K + l; } }
+    for (int c = tid & 63; c < a.D0p; c += 64) {                // a thread owns columns (pair indices computed once), 4 rows of them
+        int ref = -1, pi = 0, pj = 0;                           // ref: column in the reference's z1 order
+        if (c < FS) { const int f = c / SLOT, l = c % SLOT; if (l < K) ref = f * K + l; }
         else if (c < CB) {
             int n = c - FS, i = 0;                              // n-th pair (i, j), i < j, row-major
             while (n >= F - 1 - i) { n -= F - 1 - i; ++i; }
-            const int j = i + 1 + n;
-            float s = 0.f;
-            for (int l = 0; l < K; ++l) s = fmaf(se[r * FS + i * SLOT + l], se[r * FS + j * SLOT + l], s);
-            z = s; ref = F * K + (c - FS);
-        } else if (c == CB) { z = bval; ref = a.d0 - 1; }
-        float v = 0.f;
-        if (t < B) {
-            if (ref >= 0) {
-                const float m = a.mask ? (float)a.mask[(size_t)t * a.d0 + ref] * a.inv_keep : 1.0f;
-                v = ip_act(z, a.act) * m;
-            } else if (c == CB + 1) v = 1.0f;
+            pi = i; pj = i + 1 + n; ref = F * K + (c - FS);
+        } else if (c == CB) ref = a.d0 - 1;
+        for (int r = tid >> 6; r < 16; r += 4) {
+            const int t = t0 + r;
+            float z = 0.f;
+            if (c < FS) z = se[r * FS + c];
+            else if (c < CB) {
+                float s2 = 0.f;
+                for (int l = 0; l < K; ++l) s2 = fmaf(se[r * FS + pi * SLOT + l], se[r * FS + pj * SLOT + l], s2);
+                z = s2;
+            } else if (c == CB) z = bval;
+            float v = 0.f;
+            if (t < B) {
+                if (ref >= 0) {
+                    const float m = a.mask ? (float)a.mask[(size_t)t * a.d0 + ref] * a.inv_keep : 1.0f;
+                    v = ip_act(z, a.act) * m;
+                } else if (c == CB + 1) v = 1.0f;
+            }
+            sa[r * a.D0p + c] = v;
         }
-        sa[e] = v;
     }
     __syncthreads();
-    for (int e = tid; e < 16 * a.D0p; e += 256) a0[ft_off<T>(t0 + e / a.D0p, e % a.D0p, a.D0p)] = (T)sa[e];
+    // F layout: this workgroup's 16 rows are one row tile; a lane-slot of a fragment = EPL consecutive columns of one row
+    for (int e = tid; e < 16 * a.D0p / EPL; e += 256) {
+        const int g = e >> 4, r = e & 15;                        // column group, row
+        frag fv;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) fv[x] = (T)sa[r * a.D0p + g * EPL + x];
+        *reinterpret_cast<frag*>(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p)) = fv;
+    }
     for (int e = tid; e < a.D0p * 4; e += 256) {
         const int c = e >> 2, tq = e & 3;
         store4(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
@@ -104,7 +154,7 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
 // Inner-product layer, backward: dz1' [Ba][D0p] f32 (already times mask/keep and act') ->
 // slot-layout embedding gradients gx' [Ba][D0p] (columns 16f + l) for the sparse-row update, and the
 // per-workgroup partial of db = sum_t dz1[b].
-struct IpBwdArgs { int P; const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; int D0p; };
+struct IpBwdArgs { int P; const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; int D0p; const float* emb; };
 
 static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const float* __restrict__ dz, float* __restrict__ gxp,
                                                         float* __restrict__ gb_part)
@@ -114,14 +164,10 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
     float* sd = se + 16 * a.F * SLOT;                           // [16][D0p]
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
     const int P = a.P, CB = FS + P;
-    for (int e = tid; e < 16 * F * 4; e += 256) {
-        const int q = e & 3, f = (e >> 2) % F, r = (e >> 2) / F, t = t0 + r;
-        int64_t id = -1;
-        if (t < B) { id = a.ids[(size_t)t * F + f]; if (id < 0 || id >= a.n_rows) id = -1; }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0) v = *reinterpret_cast<const float4*>(a.table16 + (size_t)id * SLOT + 4 * q);
-        *reinterpret_cast<float4*>(se + r * FS + f * SLOT + 4 * q) = v;
-    }
+    if (a.emb) {                                                // the raw embeddings the forward gathered
+        for (int e = tid; e < 16 * FS / 4; e += 256)
+            *reinterpret_cast<float4*>(se + 4 * e) = *reinterpret_cast<const float4*>(a.emb + (size_t)t0 * FS + 4 * e);
+    } else ip_gather16(se, a.ids, a.table16, a.n_rows, t0, B, F, nullptr);
     for (int e = tid; e < 16 * a.D0p; e += 256) sd[e] = dz[(size_t)(t0 + e / a.D0p) * a.D0p + e % a.D0p];
     __syncthreads();
     for (int e = tid; e < 16 * FS; e += 256) {                   // (example r, field f, slot l)
@@ -151,28 +197,47 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
 // The epilogues compute the 4 values a lane owns (rows r0 .. r0+3 of one column); k_gemm_ft writes both
 // layouts.  Keep-masks are read TRANSPOSED ([unit][example], k_mask_T below): a lane's 4 rows are 4
 // consecutive bytes, one dword load; activations for act' come from xT the same way (one 8-byte load).
+// Transposed keep-masks are tiled like a fragment-tiled operand of bytes: 16 units x 32 examples = one 512-byte
+// block, so that a 32-example strip reads whole blocks (and a 128-row GEMM tile four of them per 16 units).
+__host__ __device__ inline size_t mask_off(int col, int row, int ldT) {
+    return ((size_t)(col >> 4) * (ldT >> 5) + (row >> 5)) * 512 + (col & 15) * 32 + (row & 31);
+}
+// Every epilogue is split in two: load() fetches what the lane's 4 values need from memory (it can be issued
+// before the product's k-loop), apply() turns the accumulator into the values; pre() is both.
 template <typename T> struct EpiIpFwd {      // a_t = mask/keep * act(l_t); ones column at d
     static constexpr bool TILE = true;
     T* outF; int ld; T* outT; int ldT; const uint8_t* maskT; float inv_keep; int act, d, B;
-    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
-        unsigned mb = 0x01010101u;
-        if (maskT && col < d) mb = *reinterpret_cast<const unsigned*>(maskT + (size_t)col * ldT + r0);
+    struct Aux { unsigned mb; };
+    __device__ Aux load(int r0, int col) const {
+        Aux x{0x01010101u};
+        if (maskT && col < d) x.mb = *reinterpret_cast<const unsigned*>(maskT + mask_off(col, r0, ldT));
+        return x;
+    }
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const { apply(load(r0, col), r0, col, acc, v); }
+    // the activation is a wave-uniform run-time value: branch on it once per fragment (or once per block, applyA)
+    __device__ void apply(const Aux& ax, int r0, int col, const f32x4& acc, float v[4]) const {
+        if (act == A_RELU) applyA<A_RELU>(ax, r0, col, acc, v);
+        else if (act == A_TANH) applyA<A_TANH>(ax, r0, col, acc, v);
+        else applyA<A_SIG>(ax, r0, col, acc, v);
+    }
+    template <int ACT> __device__ void applyA(const Aux& ax, int r0, int col, const f32x4& acc, float v[4]) const {
+        const unsigned mb = ax.mb;
+        const float sc = maskT ? inv_keep : 1.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = r0 + r;
-            float x = 0.f;
-            if (t < B) {
-                if (col < d) x = ip_act(acc[r], act) * ((float)((mb >> (8 * r)) & 0xffu) * (maskT ? inv_keep : 1.0f));
-                else if (col == d) x = 1.0f;
-            }
-            v[r] = x;
+            float x = ip_act_c<ACT>(acc[r]) * ((float)((mb >> (8 * r)) & 0xffu) * sc);
+            x = col < d ? x : (col == d ? 1.0f : 0.f);
+            v[r] = (r0 + r < B) ? x : 0.f;
         }
     }
 };
 template <typename T> struct EpiIpOut {      // logits (column 0), loss, delta = sigmoid(logit) - y
     static constexpr bool TILE = true;
     T* outF; int ld; T* outT; int ldT; const float* y; float* logits; float* loss_t; float* p_out; int B;
-    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
+    struct Aux { };
+    __device__ Aux load(int, int) const { return Aux{}; }
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const { apply(Aux{}, r0, col, acc, v); }
+    __device__ void apply(const Aux&, int r0, int col, const f32x4& acc, float v[4]) const {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = r0 + r;
@@ -191,28 +256,273 @@ template <typename T> struct EpiIpBwd {      // delta l_t = (delta l_{t+1} W^T) 
     static constexpr bool TILE = true;
     T* outF; int ld; T* outT; int ldT; float* out32; int ld32; const T* aT; const uint8_t* maskT; float inv_keep, keep; int act, d, B;
     const int* ref;          // layer 0 (out32 != null): slot column -> reference column, -1 = padding
-    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const {
-        const bool real = ref ? ref[col] >= 0 : col < d;
-        unsigned mb = 0x01010101u;
-        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (real) {
-            if (maskT) mb = *reinterpret_cast<const unsigned*>(maskT + (size_t)col * ldT + r0);
-            u = load4(aT + ft_off<T>(col, r0, ldT));
+    struct Aux { unsigned mb; float4 u; bool real; };
+    __device__ Aux load(int r0, int col) const {
+        Aux x{0x01010101u, make_float4(0.f, 0.f, 0.f, 0.f), ref ? ref[col] >= 0 : col < d};
+        if (x.real) {
+            if (maskT) x.mb = *reinterpret_cast<const unsigned*>(maskT + mask_off(col, r0, ldT));
+            x.u = load4(aT + ft_off<T>(col, r0, ldT));
         }
-        const float uu[4] = {u.x, u.y, u.z, u.w};
+        return x;
+    }
+    __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const { apply(load(r0, col), r0, col, acc, v); }
+    __device__ void apply(const Aux& ax, int r0, int col, const f32x4& acc, float v[4]) const {
+        if (act == A_RELU) applyA<A_RELU>(ax, r0, col, acc, v);
+        else if (act == A_TANH) applyA<A_TANH>(ax, r0, col, acc, v);
+        else applyA<A_SIG>(ax, r0, col, acc, v);
+    }
+    template <int ACT> __device__ void applyA(const Aux& ax, int r0, int col, const f32x4& acc, float v[4]) const {
+        const unsigned mb = ax.mb;
+        const float uu[4] = {ax.u.x, ax.u.y, ax.u.z, ax.u.w};
+        const float sc = maskT ? inv_keep : 1.0f, ks = maskT ? keep : 1.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int t = r0 + r;
-            float x = 0.f;
-            if (t < B && real) {
-                const float m = (float)((mb >> (8 * r)) & 0xffu);
-                x = acc[r] * m * (maskT ? inv_keep : 1.0f) * ip_dact_u(uu[r] * (maskT ? keep : 1.0f), act);   // act(l_t) where m = 1
-            }
+            const float m = (float)((mb >> (8 * r)) & 0xffu);
+            const float x = (r0 + r < B && ax.real) ? acc[r] * m * sc * ip_dact_u_c<ACT>(uu[r] * ks) : 0.f;   // act(l_t) where m = 1
             v[r] = x;
-            if (out32) out32[(size_t)t * ld32 + col] = x;
+            if (out32) out32[(size_t)(r0 + r) * ld32 + col] = x;
         }
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Strip kernels: the whole deep stack for a strip of 16 RT examples inside ONE workgroup, forward
+// (k_ip_strip_fwd: L + 1 products, activations, loss / output delta) and backward-data
+// (k_ip_strip_bwd: L + 1 products down to dz1).  As separate GEMM launches these products are bound by
+// fixed costs -- per launch ~4 us of launch, ~1.5 us of pipeline fill, ~5 us of epilogue writing both
+// operand layouts and ~5 us of cold operands, against 3-8 us of L2-bound main loop -- 16 times per step.
+// Here a strip's activations stay in LDS (two ping-pong tiles in fragment order, so an A fragment is
+// one conflict-free ds_read_b128 per lane), each wave owns 64-column blocks of a layer's output and
+// streams the weights (fragment-tiled, L2-resident) straight into B fragments, and only what the
+// weight-gradient products need goes to HBM: the transposed activations / deltas.  Every workgroup
+// reads every weight once per pass: 16 RT FLOP per L2 byte, which is what bounds these kernels.
+// ------------------------------------------------------------------------------------------
+constexpr int STRIP_MAXP = IPNN_MAX_HIDDEN + 1;                  // products of the stack
+template <typename T> struct StripFwdArgs {
+    const T* a0; int n;                                          // a0: F layout [Ba][Dp0]; n = L + 1
+    const T* W[STRIP_MAXP]; int Dp[STRIP_MAXP + 1];              // W[t-1] = wf[t-1]: fragment-tiled [Dp_t][Dp_{t-1}]
+    EpiIpFwd<T> ef[STRIP_MAXP]; EpiIpOut<T> eo;                  // ef[t-1], t = 1..L; eo: the output unit
+    long long* dbg;                                              // IPNN_STAMPS=1 (diagnostics): s_memtime per layer, 16 per workgroup
+};
+template <typename T> struct StripBwdArgs {
+    const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
+    const T* W[STRIP_MAXP]; int Dp[STRIP_MAXP + 1];              // W[t-1] = wb[t-1]: fragment-tiled [Dp_{t-1}][Dp_t]
+    EpiIpBwd<T> eb[STRIP_MAXP];                                  // eb[t-1]: product t -> delta l_{t-1}
+    long long* dbg;
+};
+
+// one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
+// Weights: five register stages (four k-steps in flight while one multiplies: with two waves per SIMD that
+// covers an L2 round trip at the rate the texture path delivers fragments); loads past the end are clamped
+// to the last k-step, so the loop has no branch.  The strip's own fragments come from LDS.
+template <typename T> struct StripB { typename Traits<T>::frag s[4][4]; };     // k-steps 0..3 of a block's weights, in flight
+
+template <typename T>
+__device__ __forceinline__ void strip_prefetch(StripB<T>& pb, const T* __restrict__ W, const int nkt, const int blk, const int lane)
+{
+    typedef typename Traits<T>::frag frag;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) pb.s[j][n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * 4 + n, min(j, nkt - 1), nkt, lane));
+}
+
+template <typename T, int RT>
+__device__ __forceinline__ void strip_product(f32x4 (&acc)[RT][4], StripB<T>& pb, const T* in, const T* __restrict__ W, const int nkt,
+                                              const int blk, const int lane)
+{
+    typedef typename Traits<T>::frag frag;
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag b4[4];
+    frag (&b0)[4] = pb.s[0]; frag (&b1)[4] = pb.s[1]; frag (&b2)[4] = pb.s[2]; frag (&b3)[4] = pb.s[3];
+    const int last = nkt - 1;
+    auto loadb = [&](frag* b, const int kt) {
+        const int k = min(kt, last);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * 4 + n, k, nkt, lane));
+    };
+    auto mul = [&](const int kt, const frag* b) {
+        frag a[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) a[m] = *reinterpret_cast<const frag*>(ft_frag<T>(in, m, kt, nkt, lane));
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma(acc[m][n], a[m], b[n]);
+    };
+    int kt = 0;
+    for (; kt + 5 <= nkt; kt += 5) {
+        loadb(b4, kt + 4); mul(kt, b0);
+        if (kt + 5 < nkt) loadb(b0, kt + 5);
+        mul(kt + 1, b1);
+        if (kt + 6 < nkt) loadb(b1, kt + 6);
+        mul(kt + 2, b2);
+        if (kt + 7 < nkt) loadb(b2, kt + 7);
+        mul(kt + 3, b3);
+        if (kt + 8 < nkt) loadb(b3, kt + 8);
+        mul(kt + 4, b4);
+    }
+    if (kt < nkt) mul(kt, b0);
+    if (kt + 1 < nkt) mul(kt + 1, b1);
+    if (kt + 2 < nkt) mul(kt + 2, b2);
+    if (kt + 3 < nkt) mul(kt + 3, b3);
+}
+
+// what the epilogue of a block reads from memory (keep-mask bytes, activations for act'), fetched before the k-loop
+template <typename T, int RT, typename Epi>
+__device__ __forceinline__ void strip_aux(typename Epi::Aux (&ax)[RT][4], const Epi& epi, const int row0, const int blk, const int lane)
+{
+    const int rq = 4 * (lane >> 4), cl = lane & 15;
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ax[m][n] = epi.load(row0 + m * 16 + rq, blk * 64 + n * 16 + cl);
+}
+
+// epilogue of a block: the lane's values through `epi.apply`, the transposed layout to HBM (8-byte pieces),
+// the strip's own layout to the LDS tile `out` (the next product's A operand) when there is a next product
+template <int ACT, typename T, int RT, typename Epi>
+__device__ __forceinline__ void strip_epilogue_a(f32x4 (&acc)[RT][4], const typename Epi::Aux (&ax)[RT][4], const Epi& epi, T* out, const int N,
+                                                 const int row0, const int blk, const int lane)
+{
+    const int rq = 4 * (lane >> 4), cl = lane & 15;
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v[4];
+            const int col = blk * 64 + n * 16 + cl;
+            epi.template applyA<ACT>(ax[m][n], row0 + m * 16 + rq, col, acc[m][n], v);
+            if (epi.outT) store4(epi.outT + ft_off<T>(col, row0 + m * 16 + rq, epi.ldT), v[0], v[1], v[2], v[3]);
+            if (out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[ft_off<T>(m * 16 + rq + r, col, N)] = (T)v[r];
+            }
+        }
+}
+template <typename T, int RT, typename Epi>
+__device__ __forceinline__ void strip_epilogue(f32x4 (&acc)[RT][4], const typename Epi::Aux (&ax)[RT][4], const Epi& epi, T* out, const int N,
+                                               const int row0, const int blk, const int lane)
+{   // one branch on the activation per block
+    if (epi.act == A_RELU) strip_epilogue_a<A_RELU, T, RT, Epi>(acc, ax, epi, out, N, row0, blk, lane);
+    else if (epi.act == A_TANH) strip_epilogue_a<A_TANH, T, RT, Epi>(acc, ax, epi, out, N, row0, blk, lane);
+    else strip_epilogue_a<A_SIG, T, RT, Epi>(acc, ax, epi, out, N, row0, blk, lane);
+}
+
+template <typename T> __device__ __forceinline__ void strip_load(T* dst, const T* __restrict__ src, const int nfrag16)
+{   // nfrag16 16-byte pieces, contiguous in both
+    typedef typename Traits<T>::frag frag;
+    for (int i = threadIdx.x; i < nfrag16; i += blockDim.x) reinterpret_cast<frag*>(dst)[i] = reinterpret_cast<const frag*>(src)[i];
+}
+
+#define STRIP_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+constexpr int STRIP_NW = 8;                                      // waves per strip workgroup (2 per SIMD: 256 registers each)
+// A wave's blocks of the stack in order: (product p, block w), (p, w + NW), ... then the next product it has a
+// block in.  The weights of the NEXT block are requested before the current block's epilogue (they do not
+// depend on the strip), so the barrier between two products and the epilogue hide their L2 round trip.
+struct StripItem { int p, blk; };
+template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd)
+{   // fwd: product p has Dp[p + 1] / 64 blocks (the output unit, p = n - 1: one); bwd: product index q = n - t, Dp[t - 1] / 64 blocks
+    it.blk += STRIP_NW;
+    for (;;) {
+        if (it.p >= a.n) return it;
+        const int nblk = fwd ? a.Dp[it.p + 1] / 64 : a.Dp[a.n - it.p - 1] / 64;
+        if (it.blk < nblk) return it;
+        it.p += 1; it.blk = wave;
+    }
+}
+
+template <typename T, int RT>
+static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const StripFwdArgs<T> a, const int maxD)
+{
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    extern __shared__ __align__(16) unsigned char strip_smem[];
+    T* in = reinterpret_cast<T*>(strip_smem);
+    T* out = in + (size_t)RT * 16 * maxD;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * RT * 16;
+    STRIP_STAMP(0);
+    StripB<T> pb;
+    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, true);
+    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, nx.blk, lane);
+    // the strip of a0: row tiles RT blockIdx.x .. of an F-layout operand are contiguous
+    strip_load<T>(in, a.a0 + (size_t)blockIdx.x * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
+    lds_barrier();
+    STRIP_STAMP(1);
+    f32x4 acc[RT][4];
+    for (int l = 0; l < a.n; ++l) {
+        const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
+        const bool hidden = l + 1 < a.n;
+        while (nx.p == l) {
+            const int blk = nx.blk;
+            if (hidden) {
+                typename EpiIpFwd<T>::Aux ax[RT][4];
+                strip_aux<T, RT>(ax, a.ef[l], row0, blk, lane);
+                strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                nx = strip_next(a, nx, wave, true);
+                if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, nx.blk, lane);
+                strip_epilogue<T, RT>(acc, ax, a.ef[l], out, N, row0, blk, lane);
+            } else {                                              // the output unit: logits, loss, delta (column 0)
+                strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                nx.p = a.n;
+                const int rq = 4 * (lane >> 4), cl = lane & 15;
+#pragma unroll
+                for (int m = 0; m < RT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        float v[4];
+                        const int col = n * 16 + cl, r0 = row0 + m * 16 + rq;
+                        a.eo.pre(r0, col, acc[m][n], v);
+                        if (a.eo.outT) store4(a.eo.outT + ft_off<T>(col, r0, a.eo.ldT), v[0], v[1], v[2], v[3]);
+                        if (a.eo.outF) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a.eo.outF[ft_off<T>(r0 + r, col, a.eo.ld)] = (T)v[r];
+                        }
+                    }
+            }
+        }
+        if (hidden) lds_barrier();
+        STRIP_STAMP(2 + l);
+        T* t = in; in = out; out = t;
+    }
+}
+
+template <typename T, int RT>
+static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const StripBwdArgs<T> a, const int maxD)
+{
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    extern __shared__ __align__(16) unsigned char strip_smem[];
+    T* in = reinterpret_cast<T*>(strip_smem);
+    T* out = in + (size_t)RT * 16 * maxD;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * RT * 16;
+    STRIP_STAMP(0);
+    StripB<T> pb;                                                 // item index q = n - t: product t = n - q
+    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false);
+    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, nx.blk, lane);
+    strip_load<T>(in, a.dlast + (size_t)blockIdx.x * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
+    lds_barrier();
+    STRIP_STAMP(1);
+    f32x4 acc[RT][4];
+    for (int t = a.n; t >= 1; --t) {                              // delta l_{t-1} = (delta l_t . W_t^T) * mask * act'
+        const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
+        while (nx.p == q) {
+            const int blk = nx.blk;
+            typename EpiIpBwd<T>::Aux ax[RT][4];
+            strip_aux<T, RT>(ax, a.eb[t - 1], row0, blk, lane);
+            strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
+            nx = strip_next(a, nx, wave, false);
+            if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, nx.blk, lane);
+            strip_epilogue<T, RT>(acc, ax, a.eb[t - 1], t > 1 ? out : nullptr, N, row0, blk, lane);
+        }
+        if (t > 1) lds_barrier();
+        STRIP_STAMP(2 + q);
+        T* x = in; in = out; out = x;
+    }
+}
 
 // Keep-masks [B][d] uint8 (the ABI's layout, reference column order) -> [Dp][ldT] uint8, zero padded,
 // for every layer in one launch; layer 0's columns are mapped to the slot layout on the way.
@@ -237,7 +547,7 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     __syncthreads();
     const int cc = threadIdx.x >> 2, q = threadIdx.x & 3;
     if (c0 + cc < a.Dp[t])
-        *reinterpret_cast<uint4*>(a.dst[t] + (size_t)(c0 + cc) * a.ldT + t0 + 16 * q) = *reinterpret_cast<const uint4*>(&s[cc][16 * q]);
+        *reinterpret_cast<uint4*>(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT)) = *reinterpret_cast<const uint4*>(&s[cc][16 * q]);
 }
 
 // W_t <- W_t - lr * sum of slabs; refresh both tiled shadows.  Layer 1 rows are in slot layout.
@@ -345,12 +655,17 @@ struct ipnn_handle {
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
     std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
+    float* emb = nullptr;                            // [ldT][F*16] raw embeddings of the step's examples (forward -> backward)
     float *dz0 = nullptr, *gxp = nullptr, *gb_part = nullptr, *loss_t = nullptr, *loss_dev = nullptr, *slab = nullptr;
     int* ref0 = nullptr; int* err_flag = nullptr;
     int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr; void* skeys = nullptr;
     double* cpow1 = nullptr; bool key64 = true;
     size_t slab_stride = 0;
     bool prof = false;                               // HIP-event timing of the step's segments
+    long long* stamps = nullptr;                     // IPNN_STAMPS=1: [2][Ba/16][16] time stamps of the strip kernels
+    bool group_wgrad = true;                         // IPNN_GROUP_WGRAD=0: one launch per weight-gradient product
+    bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
 };
@@ -387,22 +702,24 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const int Ba = rup(B, 256), L = h->L, F = h->F, ldT = h->ldT;
     const float keep = h->cfg.keep_prob, inv_keep = 1.0f / keep;
     const size_t lds_ip = (size_t)16 * (F * SLOT + h->Dp[0]) * sizeof(float);
-    if (train) {
-        IpProf ps(h, "sort");
+    if (train) {   // grouping of the batch's ids for the sparse-row update: depends on the ids alone, so it runs beside the stack
+        hipStream_t ss = h->st2 ? h->st2 : h->st;
+        if (h->st2) { IHK(h, hipEventRecord(h->ev_fork, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_fork, 0)); }
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
         if (h->key64) {
-            hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, h->st, so);
-            hipLaunchKernelGGL((k_sortB<unsigned long long>), dim3(16 * F), dim3(256), SORT_N * 8, h->st, so);
+            hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, ss, so);
+            hipLaunchKernelGGL((k_sortB<unsigned long long>), dim3(16 * F), dim3(256), SORT_N * 8, ss, so);
         } else {
-            hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, h->st, so);
-            hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, h->st, so);
+            hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, ss, so);
+            hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, ss, so);
         }
+        if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
     }
     {
         IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag};
-        hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0]);
+        hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
     }
     // one product: C [M][N] = A . B^T on fragment-tiled operands; narrow problems take smaller wave tiles
     auto gemm = [&](const T* A, const T* Bm, int M, int N, int nkt_all, int nkt, int splitk, auto epi) {
@@ -442,7 +759,33 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->st, ma);
     }
     constexpr int KS = Traits<T>::KS;
-    {
+    int maxD = 0;
+    for (int t = 0; t <= L + 1; ++t) maxD = std::max(maxD, h->Dp[t]);
+    constexpr int RT = sizeof(T) == 2 ? 2 : 1;                   // strip = 32 (bf16) / 16 (f32) examples: two LDS tiles of 64 KiB at 1024 units
+    const size_t strip_lds = (size_t)2 * RT * 16 * maxD * sizeof(T);
+    const bool strip = h->strip && strip_lds <= 128 * 1024;
+    if (strip) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_set = true;
+        }
+    }
+    if (strip) {
+        IpProf ps(h, "fwd");
+        StripFwdArgs<T> sa{};
+        sa.a0 = (const T*)h->a[0]; sa.n = L + 1;
+        for (int t = 0; t <= L + 1; ++t) sa.Dp[t] = h->Dp[t];
+        for (int t = 1; t <= L + 1; ++t) sa.W[t - 1] = (const T*)h->wf[t - 1];
+        for (int t = 1; t <= L; ++t)
+            sa.ef[t - 1] = EpiIpFwd<T>{nullptr, h->Dp[t], (T*)h->aT[t], ldT, drop ? h->maskT[t] : nullptr, drop ? inv_keep : 1.0f, h->cfg.act,
+                                       h->d[t], B};
+        sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
+                            logits_out, h->loss_t, p_out, B};
+        sa.dbg = h->stamps;
+        hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
+    } else {
     IpProf ps(h, "fwd");
     for (int t = 1; t <= L; ++t) {       // l_t = a_{t-1} W_t ; a_t = drop(act(l_t))
         EpiIpFwd<T> e{(T*)h->a[t], h->Dp[t], (T*)h->aT[t], ldT, drop ? h->maskT[t] : nullptr, drop ? inv_keep : 1.0f, h->cfg.act,
@@ -456,7 +799,21 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     }
     }
     if (!train) { IHK(h, hipGetLastError()); return FNN_OK; }
-    {
+    if (strip) {
+        IpProf ps(h, "bwd");
+        StripBwdArgs<T> sb{};
+        sb.dlast = (const T*)h->dl[L]; sb.n = L + 1;
+        for (int t = 0; t <= L + 1; ++t) sb.Dp[t] = h->Dp[t];
+        for (int t = 1; t <= L + 1; ++t) {
+            const bool first = (t == 1);
+            sb.W[t - 1] = (const T*)h->wb[t - 1];
+            sb.eb[t - 1] = EpiIpBwd<T>{nullptr, h->Dp[t - 1], first ? nullptr : (T*)h->dlT[t - 2], ldT, first ? h->dz0 : nullptr, h->Dp[0],
+                                       (const T*)h->aT[t - 1], drop ? h->maskT[t - 1] : nullptr, inv_keep, keep, h->cfg.act, h->d[t - 1], B,
+                                       first ? h->ref0 : nullptr};
+        }
+        sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr;
+        hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
+    } else {
     IpProf ps(h, "bwd");
     for (int t = L + 1; t >= 1; --t) {   // delta l_{t-1} from delta l_t ; then gW_t = a_{t-1}^T delta l_t
         const bool first = (t == 1);
@@ -469,6 +826,24 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {   // all weight gradients: gW_t [Dp_{t-1}][Dp_t] = a_{t-1}^T . delta l_t, contraction over the examples,
         // split-K slabs (the split chosen per layer so that every product fills the chip)
         IpProf ps(h, "wgrad");
+        if (h->group_wgrad && L + 1 <= GEMM_GROUP_MAX) {   // ONE launch for the whole stack: 128 x 128 tiles of every product, widest first
+            GemmGroupArgs g{};
+            std::vector<size_t> offs(L + 2, 0);
+            for (int t = 1; t <= L + 1; ++t) offs[t] = offs[t - 1] + (size_t)h->Dp[t - 1] * h->Dp[t];
+            std::vector<int> order(L + 1);
+            for (int t = 1; t <= L + 1; ++t) order[t - 1] = t;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return (size_t)h->Dp[x - 1] * h->Dp[x] > (size_t)h->Dp[y - 1] * h->Dp[y]; });
+            int wg = 0;
+            for (int i = 0; i <= L; ++i) {
+                const int t = order[i], sk = h->sk[t - 1], M = h->Dp[t - 1], N = h->Dp[t];
+                GemmGroupProb& pr = g.p[i];
+                pr.A = h->aT[t - 1]; pr.B = h->dlT[t - 1]; pr.out = h->slab + offs[t - 1]; pr.mt16 = M / 16; pr.nt16 = N / 16;
+                pr.nkt_all = ldT / KS; pr.nkt = Ba / KS / sk; pr.ldo = N; pr.gx = (M + 127) / 128; pr.gy = (N + 127) / 128;
+                g.wg0[i] = wg; wg += pr.gx * pr.gy * sk;
+            }
+            g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride;
+            hipLaunchKernelGGL((k_gemm_group<T, 4, 4>), dim3(wg), dim3(256), 0, h->st, g);
+        } else {
         size_t off = 0;
         for (int t = 1; t <= L + 1; ++t) {
             const int sk = h->sk[t - 1];
@@ -476,13 +851,15 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             gemm((const T*)h->aT[t - 1], (const T*)h->dlT[t - 1], h->Dp[t - 1], h->Dp[t], ldT / KS, Ba / KS / sk, sk, e);
             off += (size_t)h->Dp[t - 1] * h->Dp[t];
         }
+        }
     }
     {
         IpProf ps(h, "ip_bwd");
-        IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0]};
+        IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0], h->emb};
         hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, h->st, ba, h->dz0, h->gxp, h->gb_part);
     }
     {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
+        if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));
         IpProf ps(h, "scatter");
         // Adam: the same sorted sums land in the (zero) gradient table instead: G[row] = 0 * 1 - (-1) * sum
         ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, h->adam ? -1.0 : (double)h->cfg.lr,
@@ -542,10 +919,17 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     h->P = cfg->pairs ? h->F * (h->F - 1) / 2 : 0; h->CB = h->F * SLOT + h->P; h->bf16 = cfg->precision == FNN_PREC_BF16;
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
+    const char* side = getenv("IPNN_SIDE_STREAM");
+    if (const char* e = getenv("IPNN_GROUP_WGRAD")) h->group_wgrad = atoi(e) != 0;
     auto fail = [&](int code) { g_ip_err = h->err; ipnn_destroy(h); return code; };
 #define IK(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e2_); return fail(FNN_ERR_HIP); } } while (0)
     IK(hipSetDevice(h->dev));
     if (cfg->stream) h->st = (hipStream_t)cfg->stream; else { IK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking)); h->own_stream = true; }
+    if (!side || atoi(side) != 0) {
+        IK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+        IK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     h->d.resize(h->L + 2); h->Dp.resize(h->L + 2);
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
     for (int t = 1; t <= h->L; ++t) { h->d[t] = cfg->hidden[t - 1]; h->Dp[t] = rup(h->d[t] + 1, 64); if (h->d[t] < 1 || h->d[t] > 4095) { h->err = "hidden size out of range"; return fail(FNN_ERR_ARG); } }
@@ -581,6 +965,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT[t], Ba * h->Dp[t]));
     h->slab_stride = nw;
     IK(al((void**)&h->slab, (size_t)h->splitk * nw * 4));
+    IK(al((void**)&h->emb, Ba * h->F * SLOT * 4));
     IK(al((void**)&h->dz0, Ba * h->Dp[0] * 4)); IK(al((void**)&h->gxp, Ba * h->Dp[0] * 4));
     IK(al((void**)&h->gb_part, (Ba / 16) * 4)); IK(al((void**)&h->loss_t, Ba * 4)); IK(al((void**)&h->loss_dev, 4));
     IK(al((void**)&h->b, 4)); IK(al((void**)&h->err_flag, 4));
@@ -598,6 +983,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(hipMalloc((void**)&h->ref0, ref.size() * 4));
         IK(hipMemcpy(h->ref0, ref.data(), ref.size() * 4, hipMemcpyHostToDevice));
     }
+    if (getenv("IPNN_STAMPS")) IK(al((void**)&h->stamps, (size_t)2 * (h->ldT / 16) * 16 * 8));
     IK(hipStreamSynchronize(h->st));
 #undef IK
     *out = h;
@@ -615,10 +1001,13 @@ int ipnn_destroy(ipnn_handle* h)
     for (float* p : h->Wm) if (p) hipFree(p);
     for (float* p : h->Wv) if (p) hipFree(p);
     for (float* p : {h->tm, h->tv, h->tG, h->bmv}) if (p) hipFree(p);
-    void* ptrs[] = {h->table16, h->b, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
+    void* ptrs[] = {h->table16, h->b, h->emb, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
                     h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& kv : h->prof_ev) for (auto& p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (h->st2) { hipStreamSynchronize(h->st2); hipStreamDestroy(h->st2); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
@@ -800,6 +1189,20 @@ int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms)
     if (!h || !which || !avg_ms) return FNN_ERR_ARG;
     IHK(h, hipStreamSynchronize(h->st));
     *avg_ms = 0.0;
+    if (h->stamps && (!strcmp(which, "fwd") || !strcmp(which, "bwd"))) {      // IPNN_STAMPS=1: the last step's per-layer stamps
+        const int nwg = h->ldT / (h->bf16 ? 32 : 16), np = h->L + 3;
+        std::vector<long long> st((size_t)nwg * 16);
+        IHK(h, hipMemcpy(st.data(), h->stamps + (strcmp(which, "bwd") ? 0 : (size_t)(h->ldT / 16) * 16), st.size() * 8, hipMemcpyDeviceToHost));
+        long long t0 = st[0], t1 = 0;
+        for (int w = 0; w < nwg; ++w) { t0 = std::min(t0, st[(size_t)w * 16]); t1 = std::max(t1, st[(size_t)w * 16 + np - 1]); }
+        fprintf(stderr, "[ipnn stamps %s] %d workgroups, first start -> last end %lld ticks; avg ticks per phase (load, then products):", which, nwg, t1 - t0);
+        for (int i = 1; i < np; ++i) {
+            double s2 = 0; for (int w = 0; w < nwg; ++w) s2 += (double)(st[(size_t)w * 16 + i] - st[(size_t)w * 16 + i - 1]);
+            fprintf(stderr, " %.0f", s2 / nwg);
+        }
+        double sk = 0; for (int w = 0; w < nwg; ++w) sk += (double)(st[(size_t)w * 16] - t0);
+        fprintf(stderr, " | avg start skew %.0f\n", sk / nwg);
+    }
     auto it = h->prof_ev.find(which);
     if (it == h->prof_ev.end() || it->second.empty()) return FNN_OK;
     double tot = 0.0;
