@@ -63,8 +63,9 @@ __device__ inline void mma(f32x4& acc, const f32x4 a, const f32x4 b) {
 // Fragment-tiled operand layout for a [rows][Ktot] operand whose k index is the contraction index:
 // element (row, k) lives at ((row/16 * Ktot/KS + k/KS) * 64 + lane) * EPL + k % EPL with
 // lane = row%16 + 16 * ((k % KS) / EPL)  -- exactly the MFMA operand map above.
-template <typename T> __host__ __device__ inline size_t ft_off(int row, int k, int Ktot) {
-    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+template <typename T> __host__ __device__ inline size_t ft_off(int row_, int k_, int Ktot_) {
+    constexpr unsigned EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    const unsigned row = (unsigned)row_, k = (unsigned)k_, Ktot = (unsigned)Ktot_;     // non-negative: shifts and masks, no sign fix-ups
     return ((size_t)((row >> 4) * (Ktot / KS) + k / KS) * 64 + (row & 15) + 16 * ((k % KS) / EPL)) * EPL + (k % EPL);
 }
 // pointer to the fragment of row-tile `rt`, k-step `kt` for lane `lane`
