@@ -449,13 +449,39 @@ def bench_ipnn(args):
     if seg and any(seg.get(k, 0) > 0 for k in fl):
         dom = max(fl, key=lambda k: seg.get(k, 0.0))
         ach = fl[dom] * B / (seg[dom] * 1e-3) / 1e12
-        roof = {'kernel': 'ipnn ' + dom + ' GEMM stack', 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+        kname = {'fwd': 'k_ip_strip_fwd (deep stack forward, one launch)', 'bwd': 'k_ip_strip_bwd (deep stack backward-data, one launch)',
+                 'wgrad': 'k_gemm_group (all weight gradients, one launch)'}[dom]
+        roof = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': ach / peak, 'traffic': None, 'avg_launch_ms': seg[dom], 'algorithmic_per_example': fl[dom]}
     ach_step = flops_ex * B / (ms_per_step * 1e-3) / 1e12
     if roof is None:
         roof = {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach_step, 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': ach_step / peak, 'traffic': None, 'algorithmic_per_example': flops_ex}
     roof['step'] = {'achieved': ach_step, 'frac': ach_step / peak, 'unit': 'TFLOP/s', 'flops_per_example': flops_ex}
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the NumPy float64 restatement (oracle/ipnn_oracle.py, BLAS threads of the host) on the same batches, ~10 s
+        from oracle import ipnn_oracle as ipo
+        params = {'b': 0.0, 'W': [w.astype(np.float64) for w in Ws], 'bias': [np.zeros(d[i + 1]) for i in range(len(d) - 1)]}
+        table64 = rows.astype(np.float64)
+        mk = [m.cpu().numpy().astype(np.float64) for m in masks[0]]
+        n_done, t0c = 0, time.perf_counter()
+        while n_done < 2 or time.perf_counter() - t0c < 10.0:
+            b = n_done % NB
+            ipo.sgd_step(params, table64, ids_np[b * B:(b + 1) * B], y_np[b * B:(b + 1) * B], 'relu', 1e-4, mk, 0.5)
+            n_done += 1
+            if n_done >= 50:
+                break
+        dtc = time.perf_counter() - t0c
+        threads = 1
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([t.get('num_threads', 1) for t in threadpool_info()] or [1])
+        except Exception:
+            pass
+        cpu = {'value': n_done * B / dtc, 'unit': 'examples/sec', 'cores': threads, 'kind': 'port',
+               'sample': '%d steps of batch %d on the same ids / masks (oracle.ipnn_oracle.sgd_step: NumPy float64, BLAS on %d threads; host has %s cores)'
+                         % (n_done, B, threads, os.cpu_count())}
     print(json.dumps({
         'metric': 'examples/sec', 'value': B * args.steps / dt, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -464,7 +490,7 @@ def bench_ipnn(args):
                                'keep_prob 0.5 (mask inputs), batch %d, SGD' % B, 'per_gpu_batch': B, 'global_batch': B,
                    'parallelism': 'single'},
         'train_logloss_last_step': loss.value / B, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
-        'roofline': roof, 'cpu_baseline': None, 'kernel_ms': seg}))
+        'roofline': roof, 'cpu_baseline': cpu, 'kernel_ms': seg}))
 
 
 def pmc_traffic(kernel):

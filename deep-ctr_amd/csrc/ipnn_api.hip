@@ -695,7 +695,7 @@ struct ipnn_handle {
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
     std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
-    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
     float* emb = nullptr;                            // [ldT][F*16] raw embeddings of the step's examples (forward -> backward)
     float *dz0 = nullptr, *gxp = nullptr, *gb_part = nullptr, *loss_t = nullptr, *loss_dev = nullptr, *slab = nullptr;
     int* ref0 = nullptr; int* err_flag = nullptr;
@@ -742,9 +742,24 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const int Ba = rup(B, 256), L = h->L, F = h->F, ldT = h->ldT;
     const float keep = h->cfg.keep_prob, inv_keep = 1.0f / keep;
     const size_t lds_ip = (size_t)16 * (F * SLOT + h->Dp[0]) * sizeof(float);
-    if (train) {   // grouping of the batch's ids for the sparse-row update: depends on the ids alone, so it runs beside the stack
+    const bool drop = train && masks;
+    if (drop) for (int t = 0; t <= L; ++t) if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
+    if (train) {
+        // beside the stack, on the side stream: the transposed keep-masks (inputs of the step; needed from the first
+        // product on) and the grouping of the batch's ids for the sparse-row update (needed by the scatter)
         hipStream_t ss = h->st2 ? h->st2 : h->st;
         if (h->st2) { IHK(h, hipEventRecord(h->ev_fork, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_fork, 0)); }
+        if (drop) {   // keep-masks of all layers -> transposed, tiled, zero padded, slot-ordered for layer 0
+            MaskTArgs ma{};
+            int tiles = 0;
+            for (int t = 0; t <= L; ++t) {
+                ma.src[t] = masks[t]; ma.dst[t] = h->maskT[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
+                tiles += (Ba / 64) * (h->Dp[t] / 64);
+            }
+            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
+            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, ss, ma);
+            if (h->st2) IHK(h, hipEventRecord(h->ev_mask, h->st2));
+        }
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
         if (h->key64) {
             hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, ss, so);
@@ -786,18 +801,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL((k_gemm_ft<T, 2, 2, E>), dim3((M + 63) / 64, (N + 63) / 64, splitk), dim3(256), lds2, h->st, A, Bm,
                                mt16, nt16, nkt_all, nkt, epi);
     };
-    const bool drop = train && masks;
-    if (drop) {   // keep-masks of all layers -> transposed, padded, slot-ordered for layer 0
-        MaskTArgs ma{};
-        int tiles = 0;
-        for (int t = 0; t <= L; ++t) {
-            if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
-            ma.src[t] = masks[t]; ma.dst[t] = h->maskT[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
-            tiles += (Ba / 64) * (h->Dp[t] / 64);
-        }
-        ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
-        hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->st, ma);
-    }
+    if (drop && h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_mask, 0));     // the strips / GEMMs read the transposed masks
     constexpr int KS = Traits<T>::KS;
     int maxD = 0;
     for (int t = 0; t <= L + 1; ++t) maxD = std::max(maxD, h->Dp[t]);
@@ -969,6 +973,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (!side || atoi(side) != 0) {
         IK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
         IK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        IK(hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming));
     }
     h->d.resize(h->L + 2); h->Dp.resize(h->L + 2);
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
@@ -1051,6 +1056,7 @@ int ipnn_destroy(ipnn_handle* h)
     if (h->st2) { hipStreamSynchronize(h->st2); hipStreamDestroy(h->st2); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_mask) hipEventDestroy(h->ev_mask);
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;

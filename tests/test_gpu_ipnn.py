@@ -31,11 +31,14 @@ def problem(B, hidden, seed=0, n_rows=600, scale=0.3):
 
 
 @pytest.mark.parametrize("act,B,hidden,drop", [('relu', 50, [40, 24, 12], True), ('tanh', 130, [40, 24, 12], True),
-                                               ('sigmoid', 33, [30, 20], False), ('relu', 300, [70, 60, 50, 40, 30, 20, 10], True)])
+                                               ('sigmoid', 33, [30, 20], False), ('relu', 300, [70, 60, 50, 40, 30, 20, 10], True),
+                                               # wide layers: several 64-column blocks per wave in the strip kernels, many
+                                               # 128 x 128 tiles and K splits in the grouped weight-gradient launch
+                                               ('relu', 600, [1000, 300, 130], True), ('tanh', 257, [700, 520], False)])
 def test_ipnn_step_f32_vs_oracle(built, act, B, hidden, drop):
-    table, ids, y, params, masks, d = problem(B, hidden, seed=B)
+    table, ids, y, params, masks, d = problem(B, hidden, seed=B, scale=0.3 if max(hidden) < 200 else 0.05)
     keep = 0.7 if drop else 1.0
-    eng = IPNNEngine(F, K, hidden, act, max_batch=512, precision='f32', lr=0.01, keep_prob=keep)
+    eng = IPNNEngine(F, K, hidden, act, max_batch=max(512, B), precision='f32', lr=0.01, keep_prob=keep)
     eng.set_params(table, params['b'], params['W'], params['bias'])
     pr = eng.predict(ids).cpu().numpy()
     np.testing.assert_allclose(pr, io.predict(params, table, ids, act), rtol=2e-4, atol=1e-6)
@@ -139,4 +142,24 @@ def test_adam_steps_vs_oracle(built):
     assert np.abs(rows - table).max() <= 5e-3 * ct + 1e-7
     untouched = np.setdiff1d(np.arange(table.shape[0]), np.unique(ids))
     assert len(untouched) > 0 and np.array_equal(rows[untouched], t0[untouched].astype(np.float32))     # zero gradient, zero moments: no move
+    eng.close()
+
+
+def test_ipnn_bf16_wide_stack_tracks_oracle(built):
+    """bf16 compute on BASELINE-sized layers (1000/800/600/400, batch 1024): logits, loss and the direction of every
+    weight update follow the float64 oracle within bf16 rounding (tolerances: logits 5e-2 absolute; update cosine 0.99)."""
+    hidden = [1000, 800, 600, 400]
+    table, ids, y, params, masks, d = problem(1024, hidden, seed=11, scale=0.04)
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=1024, precision='bf16', lr=0.01, keep_prob=0.7)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    out = eng.train_step(ids, y, masks, want_logits=True)
+    p0 = [w.copy() for w in params['W']]
+    loss, logits, g = io.sgd_step(params, table, ids, y, 'relu', 0.01, [m.astype(np.float64) for m in masks], 0.7)
+    assert np.abs(out['logits'].cpu().numpy() - logits).max() < 5e-2
+    assert abs(out['loss'] - loss) <= 2e-2 * abs(loss)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        du, dv = (Ws[t] - p0[t]).ravel(), (params['W'][t] - p0[t]).ravel()
+        cos = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
+        assert cos > 0.99, (t, cos)
     eng.close()

@@ -9,7 +9,7 @@ f = glob.glob('gpurun_out/prof_ipl/**/*kernel_trace.csv', recursive=True)[0]
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
-    if 'fnn' not in n and 'k_ip' not in n and 'GLOBAL' not in n: continue
+    if 'fnn' not in n and 'k_ip' not in n and 'GLOBAL' not in n and 'k_mask' not in n: continue
     key = (n[:70], r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size'), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'))
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
     acc.setdefault(key, []).append(d)
