@@ -613,18 +613,39 @@ __device__ inline float adam_step(float w, float g, float& m, float& v, float lr
     return w - lr_t * m / (sqrtf(v) + eps);
 }
 
+// TensorFlow's FtrlOptimizer(learning_rate) as python/tf_util.py:21-24 builds it (learning_rate_power -0.5, initial
+// accumulator 0.1, l1 = l2 = 0; the ApplyFtrl kernel): state = (accum, linear).  A variable with a zero gradient keeps its
+// accumulator and linear term, and is RE-DERIVED from them: w = -linear lr / sqrt(accum) -- with the dense table gradient
+// of this graph, rows no example has touched yet drop to 0 at the first step, as they do in the reference.
+__device__ inline float ftrl_step(float w, float g, float& accum, float& linear, float lr) {
+    const float na = accum + g * g, sa = sqrtf(na);
+    linear += g - g * g / (sa + sqrtf(accum)) / lr * w;         // sqrt(na) - sqrt(accum), written without the cancellation
+    accum = na;
+    return linear != 0.f ? -linear / (sa / lr) : 0.f;
+}
+__device__ inline float opt_step(int opt, float w, float g, float& s0, float& s1, float lr, float b1, float b2, float eps) {
+    return opt == IPNN_OPT_FTRL ? ftrl_step(w, g, s0, s1, lr) : adam_step(w, g, s0, s1, lr, b1, b2, eps);
+}
+
+static __global__ void k_fill_f32(float* __restrict__ p, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // Adam on the embedding table: TensorFlow's gradient through concat / slice is DENSE (zero for
 // untouched rows), so every row's moments decay and every row moves each step -- one streaming pass
 // over table, m, v and the per-row gradient sums G (which it zeroes again for the next step).
+// (FTRL: the same pass with (accum, linear) in place of the moments.)
 static __global__ void k_adam_table(float* __restrict__ tab, float* __restrict__ m, float* __restrict__ v, float* __restrict__ G,
-                                    size_t n, float lr_t, float b1, float b2, float eps)
+                                    size_t n, float lr_t, float b1, float b2, float eps, int opt)
 {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     float4 w = *reinterpret_cast<float4*>(tab + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
     const float4 g = *reinterpret_cast<const float4*>(G + i);
-    w.x = adam_step(w.x, g.x, mm.x, vv.x, lr_t, b1, b2, eps); w.y = adam_step(w.y, g.y, mm.y, vv.y, lr_t, b1, b2, eps);
-    w.z = adam_step(w.z, g.z, mm.z, vv.z, lr_t, b1, b2, eps); w.w = adam_step(w.w, g.w, mm.w, vv.w, lr_t, b1, b2, eps);
+    w.x = opt_step(opt, w.x, g.x, mm.x, vv.x, lr_t, b1, b2, eps); w.y = opt_step(opt, w.y, g.y, mm.y, vv.y, lr_t, b1, b2, eps);
+    w.z = opt_step(opt, w.z, g.z, mm.z, vv.z, lr_t, b1, b2, eps); w.w = opt_step(opt, w.w, g.w, mm.w, vv.w, lr_t, b1, b2, eps);
     *reinterpret_cast<float4*>(tab + i) = w; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
     *reinterpret_cast<float4*>(G + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -639,7 +660,8 @@ struct IpUpdArgs {
     float* b; const float* gb_part; int ngb; const float* loss_t; int Ba; float* loss_sum;
     // Adam (python/tf_util.py:17-20, TensorFlow's AdamOptimizer): first / second moments beside every tensor;
     // lr is then lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) of this step
-    int adam; float beta1, beta2, eps; float* Wm[IPNN_MAX_HIDDEN + 1]; float* Wv[IPNN_MAX_HIDDEN + 1]; float* bmv;
+    int adam;                                        // 0 = SGD, else IPNN_OPT_ADAM / IPNN_OPT_FTRL (state = (accum, linear))
+    float beta1, beta2, eps; float* Wm[IPNN_MAX_HIDDEN + 1]; float* Wv[IPNN_MAX_HIDDEN + 1]; float* bmv;
 };
 
 template <typename T>
@@ -657,7 +679,7 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
         }
         if (threadIdx.x == 0) {
             *u.loss_sum = sl[0];
-            if (u.adam) *u.b = adam_step(*u.b, sg[0], u.bmv[0], u.bmv[1], u.lr, u.beta1, u.beta2, u.eps);
+            if (u.adam) *u.b = opt_step(u.adam, *u.b, sg[0], u.bmv[0], u.bmv[1], u.lr, u.beta1, u.beta2, u.eps);
             else *u.b -= u.lr * sg[0];
         }
         return;
@@ -673,7 +695,7 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     float w;
     if (u.adam) {
         float m = u.Wm[t][j], v = u.Wv[t][j];
-        w = adam_step(u.W[t][j], g, m, v, u.lr, u.beta1, u.beta2, u.eps);
+        w = opt_step(u.adam, u.W[t][j], g, m, v, u.lr, u.beta1, u.beta2, u.eps);
         u.Wm[t][j] = m; u.Wv[t][j] = v;
     } else w = u.W[t][j] - u.lr * g;
     u.W[t][j] = w;
@@ -688,7 +710,8 @@ struct ipnn_handle {
     ipnn_cfg cfg{}; std::string err; int dev = 0; hipStream_t st = nullptr; bool own_stream = false;
     int F = 0, K = 0, L = 0, P = 0, CB = 0, Bmax = 0, ldT = 0; bool bf16 = false; int splitk = 8;   // splitk: slab capacity
     std::vector<int> sk;                         // split-K of each layer's weight-gradient product
-    bool adam = false; int64_t adam_t = 0;       // Adam state: step count, moments of every tensor, dense row-gradient table
+    bool adam = false; int64_t adam_t = 0;       // Adam / FTRL: two state tensors beside every variable, dense row-gradient table; step count
+    bool ftrl = false;
     std::vector<float*> Wm, Wv; float *tm = nullptr, *tv = nullptr, *tG = nullptr, *bmv = nullptr;
     std::vector<int> d, Dp;                      // d[0..L+1], padded
     float* table16 = nullptr; int64_t n_rows = 0; float* b = nullptr;
@@ -914,12 +937,13 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     float lr_step = h->cfg.lr;
     if (h->adam) {
         h->adam_t += 1;
-        lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
-                          (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
+        if (!h->ftrl)
+            lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
+                              (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
         IpProf ps(h, "adam_table");
         const size_t n = (size_t)h->n_rows * SLOT;
         hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, h->table16, h->tm, h->tv, h->tG, n,
-                           lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps);
+                           lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
     }
     {
         IpProf ps(h, "update");
@@ -931,7 +955,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             off += (size_t)h->Dp[t - 1] * h->Dp[t];
         }
         u.n = L + 1; u.off[L + 1] = off; u.slab = h->slab; u.zstride = h->slab_stride; u.lr = lr_step;
-        u.adam = h->adam ? 1 : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
+        u.adam = h->adam ? (int)h->cfg.optimizer : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
         if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
         hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off + 255) / 256 + 1)), dim3(256), 0, h->st, u);
@@ -954,7 +978,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         cfg->max_batch < 1 || cfg->max_batch > 4096 || !(cfg->keep_prob > 0.f && cfg->keep_prob <= 1.f)) {
         g_ip_err = "bad shape (2..32 fields, k <= 16, 1..8 hidden layers, batch <= 4096, 0 < keep_prob <= 1)"; return FNN_ERR_ARG; }
     if (cfg->act != A_TANH && cfg->act != A_SIG && cfg->act != A_RELU) { g_ip_err = "bad act"; return FNN_ERR_ARG; }
-    if (cfg->optimizer != IPNN_OPT_SGD && cfg->optimizer != IPNN_OPT_ADAM) { g_ip_err = "bad optimizer"; return FNN_ERR_ARG; }
+    if (cfg->optimizer != IPNN_OPT_SGD && cfg->optimizer != IPNN_OPT_ADAM && cfg->optimizer != IPNN_OPT_FTRL) { g_ip_err = "bad optimizer"; return FNN_ERR_ARG; }
     if (cfg->optimizer == IPNN_OPT_ADAM && !(cfg->adam_eps > 0.f)) { g_ip_err = "Adam needs adam_eps > 0"; return FNN_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_ip_err = "no HIP device (libfnn_hip.so has no CPU fallback)"; return FNN_ERR_HIP; }
@@ -1000,14 +1024,17 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(al(&h->dl[t - 1], Ba * h->Dp[t] * tsz)); IK(al(&h->dlT[t - 1], Ba * h->Dp[t] * tsz));
     }
     for (int t = 0; t <= h->L; ++t) { IK(al(&h->a[t], Ba * h->Dp[t] * tsz)); IK(al(&h->aT[t], Ba * h->Dp[t] * tsz)); }
-    h->adam = cfg->optimizer == IPNN_OPT_ADAM;
+    h->ftrl = cfg->optimizer == IPNN_OPT_FTRL;
+    h->adam = cfg->optimizer == IPNN_OPT_ADAM || h->ftrl;          // both: per-variable state + dense table pass
     if (h->adam) {
         h->Wm.assign(h->L + 1, nullptr); h->Wv.assign(h->L + 1, nullptr);
         for (int t = 1; t <= h->L + 1; ++t) {
             const size_t n = (size_t)h->Dp[t - 1] * h->Dp[t];
             IK(al((void**)&h->Wm[t - 1], n * 4)); IK(al((void**)&h->Wv[t - 1], n * 4));
+            if (h->ftrl) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->Wm[t - 1], n, 0.1f);   // initial_accumulator_value
         }
         IK(al((void**)&h->bmv, 8));
+        if (h->ftrl) hipLaunchKernelGGL(k_fill_f32, dim3(1), dim3(64), 0, h->st, h->bmv, (size_t)1, 0.1f);
     }
     h->maskT.assign(h->L + 1, nullptr);
     for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT[t], Ba * h->Dp[t]));
@@ -1094,6 +1121,7 @@ int ipnn_set_table(ipnn_handle* h, const float* rows, int64_t n_rows)
             IHK(h, hipMalloc((void**)p, n * 4));
             IHK(h, hipMemset(*p, 0, n * 4));
         }
+        if (h->ftrl) { hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->tm, n, 0.1f); IHK(h, hipStreamSynchronize(h->st)); }
         h->adam_t = 0;
     }
     return FNN_OK;

@@ -3,7 +3,7 @@
 `IPNNEngine` is the PyTorch-ROCm plumbing; the three class names of the reference are kept as
 constructors with its `_rch_argv` layout (X_dim, X_feas, rank, h1..hN, act_func), its `forward`
 role (`train_step` / `predict`) and its `dump` keys (`W`, `V`, `b`, `h{i}_w`, `h{i}_b`).
-Categorical fields only; optimiser 'sgd' or 'adam' (python/tf_util.py:15-29; FTRL is not built)."""
+Categorical fields only; optimiser 'sgd', 'adam' or 'ftrl' (python/tf_util.py:15-29)."""
 import ctypes as C
 import pickle
 
@@ -26,7 +26,7 @@ class IPNNEngine(object):
         self.d = [n_fields * k + (n_fields * (n_fields - 1) // 2 if pairs else 0) + 1] + self.hidden + [1]
         hid = (C.c_int32 * 8)(*(self.hidden + [0] * (8 - len(self.hidden))))
         cfg = _capi.ipnn_cfg(n_fields, k, len(self.hidden), hid, _capi.IPNN_ACTS[act], 1 if pairs else 0, max_batch,
-                             1 if precision == 'bf16' else 0, lr, keep_prob, {'sgd': 0, 'adam': 1}[optimizer], adam_betas[0],
+                             1 if precision == 'bf16' else 0, lr, keep_prob, {'sgd': 0, 'adam': 1, 'ftrl': 2}[optimizer], adam_betas[0],
                              adam_betas[1], adam_eps, device, C.c_void_p(self.stream.cuda_stream))
         h = C.c_void_p()
         rc = self.lib.ipnn_create(C.byref(cfg), C.byref(h))
@@ -137,8 +137,8 @@ class _IPFamily(object):
         X_dim, X_feas, rank = _rch_argv[:3]
         hidden, act = list(_rch_argv[3:-1]), _rch_argv[-1]
         assert len(hidden) == self.N_HIDDEN
-        if _ptmzr_argv[0] not in ('sgd', 'adam'):                    # python/tf_util.py:15-29
-            raise NotImplementedError("optimizer %r: sgd and adam are built (the reference's FTRL is not)" % (_ptmzr_argv[0],))
+        if _ptmzr_argv[0] not in ('sgd', 'adam', 'ftrl'):            # python/tf_util.py:15-29 (anything else: plain gradient descent there)
+            raise NotImplementedError("optimizer %r: sgd, adam and ftrl are built" % (_ptmzr_argv[0],))
         self.keep = _reg_argv[0] if mode == 'train' else 1.0
         self.eng = IPNNEngine(X_feas, rank + 1, hidden, act, max_batch=max(batch_size, eval_size, 1), precision=precision,
                               lr=_ptmzr_argv[1], keep_prob=self.keep, pairs=self.PAIRS, optimizer=_ptmzr_argv[0],

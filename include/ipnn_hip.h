@@ -4,7 +4,7 @@
  * pattern): `forward` :102-133 (embeddings, pair-wise inner products, z1 = [e | p | b], then
  * l_{t+1} = dropout(act(l_t)) W_t + b_t with activation and inverted dropout BEFORE every matmul),
  * the loss sum(sigmoid_cross_entropy_with_logits) :82-88 and the gradient step.  Categorical
- * fields only (iPinYou shape: one id per field); optimiser: plain SGD or Adam (IPNN_OPT_*).  Dropout keep-masks are INPUTS (uint8, one per element,
+ * fields only (iPinYou shape: one id per field); optimiser: plain SGD, Adam or FTRL (IPNN_OPT_*).  Dropout keep-masks are INPUTS (uint8, one per element,
  * reference column order), NULL = no dropout (`drop_out=False`).
  *
  * Error codes are the FNN_ERR_* of fnn_hip.h; ipnn_last_error() has the message.
@@ -29,6 +29,10 @@ extern "C" {
                                    reference's choice for this family (python/baseline.py:146, lr 1e-4,
                                    eps 1e-8).  TensorFlow's gradient of the embedding tables is dense, so
                                    EVERY row's moments decay and every row moves each step             */
+#define IPNN_OPT_FTRL    2      /* python/tf_util.py:21-24 FtrlOptimizer(learning_rate): TensorFlow's
+                                   defaults (learning_rate_power -0.5, initial accumulator 0.1, l1 = l2 =
+                                   0); also a dense pass over the tables: a row no example has touched is
+                                   re-derived from its (zero) linear term, i.e. drops to 0 at step 1   */
 
 typedef struct ipnn_cfg {
     int32_t n_fields;                  /* X_feas                                             */

@@ -133,6 +133,41 @@ def adam_step(params, table, ids, y, act_name, lr, st, masks=None, keep=1.0, bet
     return loss, logits, g
 
 
+def ftrl_state(params, table, init_accum=0.1):
+    """(accum, linear) per variable: TensorFlow's FtrlOptimizer slots (initial_accumulator_value 0.1, linear 0)."""
+    a = lambda x: np.full_like(np.asarray(x, dtype=np.float64), init_accum)   # noqa: E731
+    z = lambda x: np.zeros_like(np.asarray(x, dtype=np.float64))              # noqa: E731
+    return {'W': [(a(w), z(w)) for w in params['W']], 'bias': [(a(b), z(b)) for b in params['bias']],
+            'b': [init_accum, 0.0], 'table': (a(table), z(table))}
+
+
+def ftrl_step(params, table, ids, y, act_name, lr, st, masks=None, keep=1.0):
+    """One step of tf.train.FtrlOptimizer(learning_rate) (python/tf_util.py:21-24) with TensorFlow's defaults
+    learning_rate_power = -0.5, l1 = l2 = 0 on EVERY variable (the ApplyFtrl kernel):
+        new_accum = accum + g^2;  linear += g - (sqrt(new_accum) - sqrt(accum)) / lr * var;
+        var = -linear / (sqrt(new_accum) / lr)  if |linear| > l1 = 0  else 0;  accum = new_accum.
+    The table's gradient is dense (zero rows for untouched features), so a row that no example has touched is
+    re-derived from its zero linear term: it becomes 0 at the first step.  Mutates params, table, st."""
+    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep)
+
+    def upd(theta, grad, al):
+        accum, linear = al
+        na = accum + grad * grad
+        linear[...] = linear + grad - (np.sqrt(na) - np.sqrt(accum)) / lr * theta
+        accum[...] = na
+        return np.where(linear != 0.0, -linear / (np.sqrt(na) / lr), 0.0)
+    for t in range(len(params['W'])):
+        params['W'][t] = upd(params['W'][t], g['W'][t], st['W'][t])
+        params['bias'][t] = upd(params['bias'][t], g['bias'][t], st['bias'][t])
+    ab = [np.array(st['b'][0]), np.array(st['b'][1])]
+    params['b'] = float(upd(np.array(params['b']), np.array(g['b']), ab))
+    st['b'] = [float(ab[0]), float(ab[1])]
+    gt = np.zeros_like(table)
+    np.add.at(gt, ids, g['e'])
+    table[...] = upd(table, gt, st['table'])
+    return loss, logits, g
+
+
 def predict(params, table, ids, act_name):
     logits, _ = forward(params, table, ids, act_name)
     return 1.0 / (1.0 + np.exp(-logits))

@@ -145,6 +145,32 @@ def test_adam_steps_vs_oracle(built):
     eng.close()
 
 
+def test_ftrl_steps_vs_oracle(built):
+    """FTRL as python/tf_util.py:21-24 builds it (TensorFlow defaults: accumulator 0.1, power -0.5, no l1/l2): three
+    steps against oracle.ftrl_step; every variable is re-derived from its linear term, so rows of the table that no
+    example touched are exactly 0 after the first step (dense table gradient), as in the reference's graph."""
+    table, ids, y, params, masks, d = problem(160, [40, 24, 12], seed=22)
+    eng = IPNNEngine(F, K, [40, 24, 12], 'relu', max_batch=256, precision='f32', lr=1e-2, keep_prob=0.7, optimizer='ftrl')
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    st = io.ftrl_state(params, table)
+    m64 = [m.astype(np.float64) for m in masks]
+    for step in range(3):
+        out = eng.train_step(ids, y, masks, want_logits=True)
+        loss, logits, _ = io.ftrl_step(params, table, ids, y, 'relu', 1e-2, st, m64, 0.7)
+        np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=2e-3, atol=2e-5)
+        assert abs(out['loss'] - loss) <= 1e-4 * abs(loss)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 5e-3 * np.abs(params['W'][t]).max() + 1e-7, t
+        assert np.abs(bs[t] - params['bias'][t]).max() <= 5e-3 * np.abs(params['bias'][t]).max() + 1e-7, t
+    assert abs(b - params['b']) <= 5e-3 * abs(params['b']) + 1e-7
+    rows = eng.get_rows(np.arange(table.shape[0]))
+    assert np.abs(rows - table).max() <= 5e-3 * np.abs(table).max() + 1e-7
+    untouched = np.setdiff1d(np.arange(table.shape[0]), np.unique(ids))
+    assert len(untouched) > 0 and not rows[untouched].any()
+    eng.close()
+
+
 def test_ipnn_bf16_wide_stack_tracks_oracle(built):
     """bf16 compute on BASELINE-sized layers (1000/800/600/400, batch 1024): logits, loss and the direction of every
     weight update follow the float64 oracle within bf16 rounding (tolerances: logits 5e-2 absolute; update cosine 0.99)."""

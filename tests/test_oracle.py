@@ -352,3 +352,27 @@ def test_fm_oracle_gradient_is_the_dense_sgd_of_the_loss():
         gb = (fo.loss_value(rows, 0.2 + eps, ids, y, 0.05, reduce_mean)[0] - fo.loss_value(rows, 0.2 - eps, ids, y, 0.05, reduce_mean)[0]) / (2 * eps)
         assert abs(b_new - (0.2 - 0.1 * gb)) < 1e-8
         assert abs(data - fo.loss_value(rows, 0.2, ids, y, 0.05, reduce_mean)[1]) < 1e-12
+
+
+def test_ipnn_oracle_ftrl_rule():
+    """oracle.ftrl_step restates TensorFlow's ApplyFtrl (python/tf_util.py:21-24, defaults): one variable by hand, and the
+    dense-gradient consequence for untouched rows."""
+    from oracle import ipnn_oracle as io
+    rng = np.random.RandomState(5)
+    F, K = 4, 3
+    table = rng.standard_normal((30, K)) * 0.2
+    ids = np.stack([rng.randint(0, 10, size=8) + 10 * 0 for _ in range(F)], 1)        # rows 10.. never touched
+    y = (rng.uniform(size=8) < 0.5).astype(np.float64)
+    d = [F * K + F * (F - 1) // 2 + 1, 5, 1]
+    params = {'b': 0.1, 'W': [rng.uniform(-.3, .3, (d[i], d[i + 1])) for i in range(2)], 'bias': [rng.uniform(-.1, .1, d[i + 1]) for i in range(2)]}
+    w0 = params['W'][1][2, 0]
+    _, _, g = io.loss_and_grads(params, table, ids, y, 'tanh')
+    g0 = g['W'][1][2, 0]
+    st = io.ftrl_state(params, table)
+    lr = 0.05
+    io.ftrl_step(params, table, ids, y, 'tanh', lr, st)
+    na = 0.1 + g0 * g0
+    lin = g0 - (np.sqrt(na) - np.sqrt(0.1)) / lr * w0
+    assert abs(params['W'][1][2, 0] - (-lin / (np.sqrt(na) / lr))) < 1e-15
+    assert abs(st['W'][1][0][2, 0] - na) < 1e-15 and abs(st['W'][1][1][2, 0] - lin) < 1e-15
+    assert not table[10:].any() and table[:10].any()
