@@ -282,6 +282,32 @@ def bench_rbm(args):
         sparse_pass()
     torch.cuda.synchronize(dev)
     dt_sp = (time.perf_counter() - t0) / n_sp
+    # mini-batch mode of the sparse layer (rbm_sparse_batch; not the reference's schedule): 16 mini-batches of 4096
+    NBm = 16
+    ids_b = np.sort(2 * synth.zipf_ids(NBm * N, sizes, 1.1, 6).astype(np.int64) % (D - 2) + 1, axis=1)
+    vid_b = np.empty((NBm * N, S), np.int32); vid_b[:, 0::2] = ids_b - 1; vid_b[:, 1::2] = ids_b
+    vid_b.sort(axis=1)
+    vval_b = ((vid_b % 2) == 1).astype(np.uint8)
+    vidb_d, vvalb_d = torch.as_tensor(vid_b).to(dev), torch.as_tensor(vval_b).to(dev)
+    unif_b = torch.rand((NBm * N, H0), device=dev)
+    dW = torch.zeros_like(W); dvis = torch.zeros_like(vb)
+
+    def batch_pass():
+        rc = lib.rbm_sparse_batch(W.data_ptr(), dW.data_ptr(), vb.data_ptr(), dvis.data_ptr(), hb.data_ptr(), ws.data_ptr(),
+                                  vidb_d.data_ptr(), vvalb_d.data_ptr(), unif_b.data_ptr(), NBm * N, N, H0, S, 2e-4, 1e-4, 1e-4, 1e-4, 0.9,
+                                  C.byref(err), st)
+        if rc != 0:
+            raise RuntimeError(lib.rbm_last_error().decode())
+    batch_pass()
+    torch.cuda.synchronize(dev)
+    n_b = max(2, args.steps // 20)
+    t0 = time.perf_counter()
+    for _ in range(n_b):
+        batch_pass()
+    torch.cuda.synchronize(dev)
+    dt_b = (time.perf_counter() - t0) / n_b / NBm               # per mini-batch of 4096
+    per_ex_b = S * H0 * 4 * 5 + S * 8 + H0 * 4                 # rows read, dW RMW twice (add, grab), W RMW
+    del dW, dvis
     # dense CD-1 layer 200 -> 300
     h = C.c_void_p()
     if lib.rbm_dense_create(H0, H1, N, 1 if args.precision == 'bf16' else 0, 0, st, C.byref(h)) != 0:
@@ -307,6 +333,9 @@ def bench_rbm(args):
         'roofline': {'kernel': 'k_rbm_sparse', 'bound': 'hbm', 'achieved': per_ex * N / dt_sp / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': per_ex * N / dt_sp / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_per_example': per_ex,
                      'note': 'latency-bound by construction: example n reads the rows example n-1 wrote'},
+        'sparse_minibatch_4096': {'examples_per_sec': N / dt_b, 'ms_per_minibatch': dt_b * 1e3, 'hbm_GBs': per_ex_b * N / dt_b / 1e9,
+                                  'frac_of_hbm_peak': per_ex_b * N / dt_b / 1e9 / HBM_PEAK_GBS, 'algorithmic_per_example': per_ex_b,
+                                  'note': 'rbm_sparse_batch: every example of a mini-batch reads start-of-batch parameters (NOT the reference schedule)'},
         'dense_cd1_200x300': {'examples_per_sec': N / dt_de, 'ms_per_minibatch_of_4096': dt_de * 1e3, 'dtype': args.precision},
         'cpu_baseline': None}))
 

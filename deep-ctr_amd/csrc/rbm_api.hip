@@ -3,6 +3,7 @@
 // (Atomu2014/deep-ctr): sparse online CD-1 (:294-508) and dense mini-batch CD-1 (:10-291).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,6 +101,129 @@ __global__ __launch_bounds__(256) void k_rbm_sparse(const SparseArgs a)
 #pragma unroll
     for (int j = 0; j < 32; ++j) if (act && j < S) a.wstep[(size_t)j * H + tid] = ws[j];
     if (tid == 0 && a.sq_err) *a.sq_err = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// Mini-batch variant of A7 (SURVEY 8d config 5 "batched mode for throughput"; NOT the reference's schedule, which is
+// online -- for a mini-batch of 1 the two coincide).  All M examples of a mini-batch read the parameters as they
+// were at its start:
+//     step_e[j]    = ((v_ej hid_e - vis_ej hid2_e) - weightcost W[f_ej]) rate_w          (as :447-453)
+//     W[f_ej]     += 2 (momentum wstep[j] + step_e[j])                                    (:454-462, per example)
+//     wstep[j]     = momentum wstep[j] + mean_e step_e[j]                                 (the positional buffer)
+//     visbias[f_ej] += (v_ej - vis_ej) rate_vis ;  hidbias += rate_hid sum_e (hid_e - hid2_e)
+// k_rbm_batch: one workgroup per example slot (thread = hidden unit), examples e = blockIdx, + gridDim, ...;
+// row deltas are ACCUMULATED into dW / dvis (zero outside this function) with float atomics, so that no example
+// reads a row another one has already moved; k_rbm_apply then moves every touched row once (grab-and-zero);
+// k_rbm_batch_tail reduces the per-workgroup partials of wstep / hidbias / error in a fixed order.  The row sums
+// depend on the order the atomics land in (rounding only): this mode is not bit-reproducible, the online one is.
+// ------------------------------------------------------------------------------------------
+struct BatchArgs {
+    const float *W, *visbias, *hidbias, *wstep; float *dW, *dvis; const int32_t* vid; const uint8_t* vval; const float* unif;
+    int M, H, S; float wcost, r_vis, r_w, mom; float* part_w; float* part_h; double* part_e;
+};
+
+__global__ __launch_bounds__(256) void k_rbm_batch(const BatchArgs a)
+{
+    __shared__ float s_w[32][257];
+    __shared__ float s_hs[256], s_vis[32], s_v[32], s_e[32];
+    __shared__ int s_id[32];
+    const int tid = threadIdx.x, H = a.H, S = a.S;
+    const bool act = tid < H;
+    const float hb = act ? a.hidbias[tid] : 0.f;
+    float ws0[32], wsum[32], hacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { ws0[j] = (act && j < S) ? a.mom * a.wstep[(size_t)j * H + tid] : 0.f; wsum[j] = 0.f; }
+    double err = 0.0;
+    for (int n = blockIdx.x; n < a.M; n += gridDim.x) {
+        if (tid < 32) {
+            s_id[tid] = tid < S ? a.vid[(size_t)n * S + tid] : 0;
+            s_v[tid] = tid < S ? (float)a.vval[(size_t)n * S + tid] : 0.f;
+        }
+        __syncthreads();
+        float wc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wc[j] = (act && j < S) ? a.W[(size_t)s_id[j] * H + tid] : 0.f;
+        float z = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z = fmaf(s_v[j], wc[j], z);
+        const float hid = sigm(z);
+        const float u = act ? a.unif[(size_t)n * H + tid] : 2.f;
+        s_hs[tid] = act ? ((u < hid) ? 1.0f : floorf(hid)) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_w[j][tid] = wc[j];
+        __syncthreads();
+        {
+            const int j = tid >> 3, seg = tid & 7;
+            float acc = 0.f;
+            for (int i = seg; i < H; i += 8) acc = fmaf(s_hs[i], s_w[j][i], acc);
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            if (seg == 0) {
+                const float vj = j < S ? sigm(acc + a.visbias[s_id[j]]) : 0.f;
+                s_vis[j] = vj;
+                const float d = vj - s_v[j];
+                s_e[j] = j < S ? d * d : 0.f;
+                if (j < S) atomicAdd(a.dvis + s_id[j], (s_v[j] - vj) * a.r_vis);
+            }
+        }
+        __syncthreads();
+        float z2 = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z2 = fmaf(s_vis[j], wc[j], z2);
+        const float hid2 = sigm(z2);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float step = ((s_v[j] * hid - s_vis[j] * hid2) - a.wcost * wc[j]) * a.r_w;
+            wsum[j] += step;
+            if (act && j < S) atomicAdd(a.dW + (size_t)s_id[j] * H + tid, 2.0f * (ws0[j] + step));
+        }
+        hacc += hid - hid2;
+        if (tid == 0) { float e = 0.f; for (int j = 0; j < 32; ++j) e += s_e[j]; err += (double)e; }
+        __syncthreads();
+    }
+    if (act) {
+        a.part_h[(size_t)blockIdx.x * H + tid] = hacc;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (j < S) a.part_w[((size_t)blockIdx.x * S + j) * H + tid] = wsum[j];
+    }
+    if (tid == 0) a.part_e[blockIdx.x] = err;
+}
+
+// every (example, slot) of the mini-batch: take the row's accumulated delta (the first taker gets it all, later ones 0)
+__global__ __launch_bounds__(256) void k_rbm_apply(float* __restrict__ W, float* __restrict__ dW, float* __restrict__ visbias,
+                                                   float* __restrict__ dvis, const int32_t* __restrict__ vid, int M, int H, int S)
+{
+    const int n = blockIdx.x / S, j = blockIdx.x % S;
+    if (n >= M) return;
+    const size_t f = (size_t)vid[(size_t)n * S + j];
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float d = atomicExch(dW + f * H + i, 0.f);
+        if (d != 0.f) atomicAdd(W + f * H + i, d);
+    }
+    if (threadIdx.x == 0) {
+        const float d = atomicExch(dvis + f, 0.f);
+        if (d != 0.f) atomicAdd(visbias + f, d);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rbm_batch_tail(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ part_w,
+                                                        const float* __restrict__ part_h, const double* __restrict__ part_e, int nwg, int M,
+                                                        int H, int S, float mom, float r_hid, double* __restrict__ err_acc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;              // element of [S][H], then of [H]
+    if (i < S * H) {
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += part_w[(size_t)w * S * H + i];
+        wstep[i] = mom * wstep[i] + s / (float)M;
+    } else if (i < S * H + H) {
+        const int hcol = i - S * H;
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += part_h[(size_t)w * H + hcol];
+        hidbias[hcol] += r_hid * s;
+    } else if (i == S * H + H) {
+        double e = 0.0;
+        for (int w = 0; w < nwg; ++w) e += part_e[w];
+        *err_acc += e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -317,6 +441,38 @@ int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep, con
     RCK(hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st));
     RCK(hipStreamSynchronize(st));
     hipFree(d_err);
+    if (sq_err_out) *sq_err_out = e;
+    return FNN_OK;
+}
+
+int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep, const int32_t* vid,
+                     const uint8_t* vval, const float* unif, int64_t N, int M, int H, int S, float weightcost, float rate_vis,
+                     float rate_hid, float rate_w, float momentum, double* sq_err_out, void* stream)
+{
+    if (!W || !dW || !visbias || !dvis || !hidbias || !wstep || !vid || !vval || !unif) RFAIL(FNN_ERR_ARG, "null pointer");
+    if (H < 1 || H > 256 || S < 1 || S > 32 || N < 1 || M < 1) RFAIL(FNN_ERR_ARG, "need 1 <= H <= 256, 1 <= S <= 32, N >= 1, M >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nwg_max = (int)std::min<int64_t>(M, 1024);       // 4 workgroups per CU; more examples than that: several per workgroup
+    float *part_w = nullptr, *part_h = nullptr; double *part_e = nullptr, *d_err = nullptr;
+    RCK(hipMalloc((void**)&part_w, (size_t)nwg_max * S * H * 4)); RCK(hipMalloc((void**)&part_h, (size_t)nwg_max * H * 4));
+    RCK(hipMalloc((void**)&part_e, (size_t)nwg_max * 8)); RCK(hipMalloc((void**)&d_err, 8));
+    RCK(hipMemsetAsync(d_err, 0, 8, st));
+    for (int64_t n0 = 0; n0 < N; n0 += M) {
+        const int m = (int)std::min<int64_t>(M, N - n0), nwg = std::min(m, nwg_max);
+        BatchArgs a{W, visbias, hidbias, wstep, dW, dvis, vid + n0 * S, vval + n0 * S, unif + n0 * H, m, H, S, weightcost, rate_vis, rate_w,
+                    momentum, part_w, part_h, part_e};
+        hipLaunchKernelGGL(k_rbm_batch, dim3(nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
+        hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 1 + 255) / 256)), dim3(256), 0, st, wstep, hidbias, part_w, part_h,
+                           part_e, nwg, m, H, S, momentum, rate_hid, d_err);
+    }
+    RCK(hipGetLastError());
+    double e = 0;
+    RCK(hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st));
+    RCK(hipStreamSynchronize(st));
+    hipFree(part_w); hipFree(part_h); hipFree(part_e); hipFree(d_err);
     if (sq_err_out) *sq_err_out = e;
     return FNN_OK;
 }

@@ -65,10 +65,11 @@ def dense_active_ids(lines, n_fields=16):
     return out
 
 
-def get_rbm_weights(file, arr, ncases, fm_model_file=None, batch_size=1, epochs=3, precision='f32', device=0):
+def get_rbm_weights(file, arr, ncases, fm_model_file=None, batch_size=1, epochs=3, precision='f32', device=0, sparse_minibatch=1):
     """:510-543.  arr = [x_dim, H0, H1, H2]; returns [W0, hb0, W1, hb1, W2, hb2] (NumPy float64
     arrays, as the caller pickles them, python/SNN_RBM.py:82-88).  weightcost 2e-4, rates 1e-4,
-    momentum 0.9 (:405-411, :159-166)."""
+    momentum 0.9 (:405-411, :159-166).  sparse_minibatch > 1: the sparse layer in mini-batches (rbm_sparse_batch;
+    NOT the reference's online schedule -- a throughput mode, see include/rbm_hip.h)."""
     import torch
     lib = _capi.load()
     dev = torch.device('cuda', device)
@@ -98,9 +99,16 @@ def get_rbm_weights(file, arr, ncases, fm_model_file=None, batch_size=1, epochs=
             for _ in range(epochs):
                 unif = t32(rng.uniform(size=(N, col)))                           # one (1,H) draw per line (:441)
                 err = C.c_double()
-                _check(lib, lib.rbm_sparse_epoch(Wd.data_ptr(), vbd.data_ptr(), hbd.data_ptr(), ws.data_ptr(),
-                                                 vid_d.data_ptr(), vval_d.data_ptr(), unif.data_ptr(), N, col, 32,
-                                                 wc, rate, rate, rate, mom, C.byref(err), st))
+                if sparse_minibatch > 1:
+                    if _ == 0:
+                        dW, dvis = torch.zeros_like(Wd), torch.zeros_like(vbd)
+                    _check(lib, lib.rbm_sparse_batch(Wd.data_ptr(), dW.data_ptr(), vbd.data_ptr(), dvis.data_ptr(), hbd.data_ptr(),
+                                                     ws.data_ptr(), vid_d.data_ptr(), vval_d.data_ptr(), unif.data_ptr(), N,
+                                                     int(sparse_minibatch), col, 32, wc, rate, rate, rate, mom, C.byref(err), st))
+                else:
+                    _check(lib, lib.rbm_sparse_epoch(Wd.data_ptr(), vbd.data_ptr(), hbd.data_ptr(), ws.data_ptr(),
+                                                     vid_d.data_ptr(), vval_d.data_ptr(), unif.data_ptr(), N, col, 32,
+                                                     wc, rate, rate, rate, mom, C.byref(err), st))
                 print("Done epoch: MSE=%f" % (err.value / ncases))
             results.append(Wd.cpu().numpy().astype(np.float64))
             results.append(hbd.cpu().numpy().astype(np.float64))

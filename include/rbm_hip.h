@@ -39,6 +39,18 @@ int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep,
                      int64_t N, int H, int S, float weightcost, float rate_vis, float rate_hid,
                      float rate_w, float momentum, double* sq_err_out, void* stream);
 
+/* Mini-batch variant of the sparse CD-1 pass -- NOT the reference's schedule (which is online; SURVEY 8d lists a
+ * batched mode for throughput); for M = 1 it is the same arithmetic as rbm_sparse_epoch.  The N examples are taken in
+ * mini-batches of M; every example of a mini-batch reads the parameters as they were at its start:
+ *     step_e[j] as in :447-453;  W[f_ej] += 2 (momentum wstep[j] + step_e[j]);  wstep[j] = momentum wstep[j] + mean_e step_e[j];
+ *     visbias[f_ej] += (v_ej - vis_ej) rate_vis;  hidbias += rate_hid sum_e (hid_e - hid2_e).
+ * dW [n_vis, H] and dvis [n_vis] are scratch accumulators owned by the caller: all zero on entry, all zero on return.
+ * Row sums are accumulated with float atomics: results are reproducible only up to the rounding of those sums. */
+int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep,
+                     const int32_t* vid, const uint8_t* vval, const float* unif,
+                     int64_t N, int M, int H, int S, float weightcost, float rate_vis, float rate_hid,
+                     float rate_w, float momentum, double* sq_err_out, void* stream);
+
 /* Dense CD-1 (RBM + CDTrainer).  The handle owns the parameters [W | visbias | hidbias]
  * (python :13-26), the momentum buffer (:166) and the work buffers for up to max_n rows. */
 typedef struct rbm_handle rbm_handle;

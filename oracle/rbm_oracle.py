@@ -83,6 +83,35 @@ def sparse_cd1_example(st, keys, v, rng, weightcost=0.0002, rates=(1e-4, 1e-4, 1
     return float(((vis - v) ** 2).sum())
 
 
+def sparse_cd1_minibatch(st, batch, rng, weightcost=0.0002, rates=(1e-4, 1e-4, 1e-4), momentum=0.9):
+    """Mini-batch variant of sparse_cd1_example (include/rbm_hip.h rbm_sparse_batch; NOT the reference's schedule,
+    which is online -- for a batch of one the two coincide).  batch: list of (keys, v).  Every example reads the
+    parameters as they were at the start of the batch; W[f_ej] += 2 (momentum weightstep[j] + step_e[j]); the
+    positional buffer becomes momentum weightstep + mean_e step_e.  Uniforms are drawn example by example, in order."""
+    vis_rate, hid_rate, w_rate = rates
+    W0, vb0, hb0, ws0 = st.W.copy(), st.visbias.copy(), st.hidbias.copy(), st.weightstep.copy()
+    step_sum = np.zeros_like(ws0)
+    hacc = np.zeros_like(hb0)
+    err = 0.0
+    for keys, v in batch:
+        keys = list(keys)
+        v = np.asarray(v, dtype=np.float64).reshape(1, -1)
+        Ws = W0[keys]
+        hid = _sigmoid(v @ Ws + hb0)
+        hid_s = binary_threshold(hid, rng)
+        vis = _sigmoid(hid_s @ Ws.T + vb0[keys])
+        hid2 = _sigmoid(vis @ Ws + hb0)
+        step = (v.T @ hid - vis.T @ hid2 - weightcost * Ws) * w_rate
+        step_sum += step
+        np.add.at(st.W, keys, 2.0 * (momentum * ws0 + step))
+        np.add.at(st.visbias, keys, (v[0] - vis[0]) * vis_rate)
+        hacc += (hid - hid2).sum(axis=0)
+        err += float(((vis - v) ** 2).sum())
+    st.weightstep = momentum * ws0 + step_sum / len(batch)
+    st.hidbias = hb0 + hid_rate * hacc
+    return err
+
+
 def sparse_cd_train(st, lines_feats, rng, epochs=3, ncases=None, **kw):
     """sparse_CDTrainer.train over `lines_feats` (a list of feature-id lists, file order)."""
     ncases = ncases or len(lines_feats)

@@ -63,6 +63,56 @@ def test_dense_cd1_minibatches_and_bf16(built, tmp_path):
         gbrbm.get_rbm_weights(path, arr, ncases=250, batch_size=125)       # empty last batch in the reference
 
 
+def test_sparse_minibatch_mode(built, tmp_path):
+    """rbm_sparse_batch (the throughput mode; not the reference's schedule): with mini-batches of 1 it is the online
+    trainer; with mini-batches of 64 it follows oracle.sparse_cd1_minibatch (float atomics: tolerance on the change)."""
+    import ctypes as C
+    import torch
+    from deep_ctr_amd import _capi
+    path, lines_feats, x_dim = make_lines(tmp_path, n=200)
+    lib, H, S = _capi.load(), 40, 32
+    vid, vval = gbrbm.sparse_inputs(gbrbm.parse_lines(path))
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for M in (1, 64):
+        rng = np.random.RandomState(5)
+        ost = ro.SparseRBMState(x_dim, H, S, rng)
+        W0 = ost.W.copy()
+        Wd = torch.as_tensor(ost.W.astype(np.float32)).to(dev); vb = torch.as_tensor(ost.visbias.astype(np.float32)).to(dev)
+        hb = torch.as_tensor(ost.hidbias.astype(np.float32)).to(dev)
+        ws = torch.zeros((S, H), dtype=torch.float32, device=dev)
+        dW, dvis = torch.zeros_like(Wd), torch.zeros_like(vb)
+        unif = rng.uniform(size=(len(lines_feats), H))
+        ud = torch.as_tensor(unif.astype(np.float32)).to(dev)
+        err = C.c_double()
+        vid_d, vval_d = torch.as_tensor(vid).to(dev).contiguous(), torch.as_tensor(vval).to(dev).contiguous()   # held until the call returns
+        assert vid_d.shape == (len(lines_feats), S) and vid_d.dtype == torch.int32 and vval_d.dtype == torch.uint8
+        rc = lib.rbm_sparse_batch(Wd.data_ptr(), dW.data_ptr(), vb.data_ptr(), dvis.data_ptr(), hb.data_ptr(), ws.data_ptr(),
+                                  vid_d.data_ptr(), vval_d.data_ptr(), ud.data_ptr(),
+                                  len(lines_feats), M, H, S, 2e-4, 1e-4, 1e-4, 1e-4, 0.9, C.byref(err), st)
+        assert rc == 0, lib.rbm_last_error()
+
+        class Replay(object):                       # the oracle draws uniform(size=(1, H)) per example: replay the same numbers
+            def __init__(self):
+                self.i = 0
+
+            def uniform(self, size=None):
+                self.i += 1
+                return unif[self.i - 1].reshape(size)
+        rp, e_ref = Replay(), 0.0
+        dicts = [ro.sparse_line_dict(f) for f in lines_feats]
+        if M == 1:
+            for keys, v in dicts:
+                e_ref += ro.sparse_cd1_example(ost, keys, v, rp)
+        else:
+            for n0 in range(0, len(dicts), M):
+                e_ref += ro.sparse_cd1_minibatch(ost, dicts[n0:n0 + M], rp)
+        assert rel_change_err(Wd.cpu().numpy().astype(np.float64), ost.W, W0) < 2e-3, M
+        np.testing.assert_allclose(ws.cpu().numpy(), ost.weightstep, rtol=2e-3, atol=1e-9)
+        assert abs(err.value - e_ref) <= 1e-4 * e_ref
+        assert not dW.any().item() and not dvis.any().item()          # the scratch accumulators come back zero
+
+
 def test_sparse_needs_32_visibles(built, tmp_path):
     p = tmp_path / 'bad.txt'
     p.write_text('0 5:1 6:1 9:1\n')

@@ -376,3 +376,21 @@ def test_ipnn_oracle_ftrl_rule():
     assert abs(params['W'][1][2, 0] - (-lin / (np.sqrt(na) / lr))) < 1e-15
     assert abs(st['W'][1][0][2, 0] - na) < 1e-15 and abs(st['W'][1][1][2, 0] - lin) < 1e-15
     assert not table[10:].any() and table[:10].any()
+
+
+def test_rbm_oracle_minibatch_of_one_is_the_online_trainer():
+    """oracle.sparse_cd1_minibatch with batches of one example reproduces sparse_cd1_example exactly (the mini-batch mode
+    generalises the reference's online update; it is not the reference's schedule for M > 1)."""
+    from oracle import rbm_oracle as ro
+    rng = np.random.RandomState(2)
+    feats = [sorted(rng.choice(np.arange(1, 60, 2), size=16, replace=False).tolist()) for _ in range(12)]
+    a = ro.SparseRBMState(62, 10, 32, np.random.RandomState(9))
+    b = ro.SparseRBMState(62, 10, 32, np.random.RandomState(9))
+    ra, rb = np.random.RandomState(4), np.random.RandomState(4)
+    for f in feats:
+        keys, v = ro.sparse_line_dict(f)
+        ea = ro.sparse_cd1_example(a, keys, v, ra)
+        eb = ro.sparse_cd1_minibatch(b, [(keys, v)], rb)
+        assert abs(ea - eb) < 1e-12
+    for x, y in ((a.W, b.W), (a.visbias, b.visbias), (a.hidbias, b.hidbias), (a.weightstep, b.weightstep)):
+        np.testing.assert_allclose(x, y, rtol=0, atol=1e-15)
