@@ -718,7 +718,7 @@ struct ipnn_handle {
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
     std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
-    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr, ev_bwd = nullptr, ev_ipb = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
     float* emb = nullptr;                            // [ldT][F*16] raw embeddings of the step's examples (forward -> backward)
     float *dz0 = nullptr, *gxp = nullptr, *gb_part = nullptr, *loss_t = nullptr, *loss_dev = nullptr, *slab = nullptr;
     int* ref0 = nullptr; int* err_flag = nullptr;
@@ -735,12 +735,12 @@ struct ipnn_handle {
 
 namespace {
 struct IpProf {                                      // one segment of ip_run on the handle's stream
-    ipnn_handle* h; const char* name; hipEvent_t b = nullptr, e = nullptr;
-    IpProf(ipnn_handle* h_, const char* n) : h(h_), name(n) {
+    ipnn_handle* h; const char* name; hipStream_t s; hipEvent_t b = nullptr, e = nullptr;
+    IpProf(ipnn_handle* h_, const char* n, hipStream_t s_ = nullptr) : h(h_), name(n), s(s_ ? s_ : h_->st) {
         if (!h->prof) return;
-        hipEventCreate(&b); hipEventCreate(&e); hipEventRecord(b, h->st);
+        hipEventCreate(&b); hipEventCreate(&e); hipEventRecord(b, s);
     }
-    ~IpProf() { if (!h->prof) return; hipEventRecord(e, h->st); h->prof_ev[name].emplace_back(b, e); }
+    ~IpProf() { if (!h->prof) return; hipEventRecord(e, s); h->prof_ev[name].emplace_back(b, e); }
 };
 }
 
@@ -791,7 +791,6 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, ss, so);
             hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, ss, so);
         }
-        if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
     }
     {
         IpProf ps(h, "ip_fwd");
@@ -890,6 +889,38 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         gemm((const T*)h->dl[t - 1], (const T*)h->wb[t - 1], Ba, h->Dp[t - 1], h->Dp[t] / KS, h->Dp[t] / KS, 1, e);
     }
     }
+    // Beside the weight gradients, on the side stream (after the id grouping, in stream order): the backward of the inner
+    // products and the sparse-row update -- they need dz1 only, the weight gradients need the transposed operands only.
+    float lr_step = h->cfg.lr;
+    {
+        hipStream_t ss = h->st2 ? h->st2 : h->st;
+        if (h->st2) { IHK(h, hipEventRecord(h->ev_bwd, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_bwd, 0)); }
+        {
+            IpProf ps(h, "ip_bwd", ss);
+            IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0], h->emb};
+            hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, ss, ba, h->dz0, h->gxp, h->gb_part);
+        }
+        if (h->st2) IHK(h, hipEventRecord(h->ev_ipb, h->st2));                 // gb_part: the update launch reads it
+        {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
+            IpProf ps(h, "scatter", ss);
+            // Adam / FTRL: the same sorted sums land in the (zero) gradient table instead: G[row] = 0 * 1 - (-1) * sum
+            ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, h->adam ? -1.0 : (double)h->cfg.lr,
+                        h->adam ? h->tG : h->table16, h->part, h->owner_cnt, h->owners, SLOT};
+            hipLaunchKernelGGL(k_scat1, dim3(F * SORT_N / 256), dim3(256), 0, ss, sa);
+            hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, ss, sa);
+        }
+        if (h->adam) {
+            h->adam_t += 1;
+            if (!h->ftrl)
+                lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
+                                  (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
+            IpProf ps(h, "adam_table", ss);
+            const size_t n = (size_t)h->n_rows * SLOT;
+            hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ss, h->table16, h->tm, h->tv, h->tG, n,
+                               lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
+        }
+        if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
+    }
     {   // all weight gradients: gW_t [Dp_{t-1}][Dp_t] = a_{t-1}^T . delta l_t, contraction over the examples,
         // split-K slabs (the split chosen per layer so that every product fills the chip)
         IpProf ps(h, "wgrad");
@@ -920,31 +951,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         }
         }
     }
-    {
-        IpProf ps(h, "ip_bwd");
-        IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0], h->emb};
-        hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, h->st, ba, h->dz0, h->gxp, h->gb_part);
-    }
-    {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
-        if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));
-        IpProf ps(h, "scatter");
-        // Adam: the same sorted sums land in the (zero) gradient table instead: G[row] = 0 * 1 - (-1) * sum
-        ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->Dp[0], h->cpow1, h->adam ? -1.0 : (double)h->cfg.lr,
-                    h->adam ? h->tG : h->table16, h->part, h->owner_cnt, h->owners, SLOT};
-        hipLaunchKernelGGL(k_scat1, dim3(F * SORT_N / 256), dim3(256), 0, h->st, sa);
-        hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, sa);
-    }
-    float lr_step = h->cfg.lr;
-    if (h->adam) {
-        h->adam_t += 1;
-        if (!h->ftrl)
-            lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
-                              (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
-        IpProf ps(h, "adam_table");
-        const size_t n = (size_t)h->n_rows * SLOT;
-        hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, h->table16, h->tm, h->tv, h->tG, n,
-                           lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
-    }
+    if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_ipb, 0));
     {
         IpProf ps(h, "update");
         size_t off = 0;
@@ -960,6 +967,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
         hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off + 255) / 256 + 1)), dim3(256), 0, h->st, u);
     }
+    if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
     IHK(h, hipGetLastError());
     return FNN_OK;
 }
@@ -998,6 +1006,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
         IK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         IK(hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming));
+        IK(hipEventCreateWithFlags(&h->ev_bwd, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_ipb, hipEventDisableTiming));
     }
     h->d.resize(h->L + 2); h->Dp.resize(h->L + 2);
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
@@ -1084,6 +1093,8 @@ int ipnn_destroy(ipnn_handle* h)
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mask) hipEventDestroy(h->ev_mask);
+    if (h->ev_bwd) hipEventDestroy(h->ev_bwd);
+    if (h->ev_ipb) hipEventDestroy(h->ev_ipb);
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
