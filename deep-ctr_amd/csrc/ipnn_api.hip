@@ -684,24 +684,34 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
         }
         return;
     }
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // 4 consecutive elements of one row per thread (layer sizes and row lengths are multiples of 64): 16-byte slab /
+    // master / state accesses, one 8-byte piece of the backward shadow, four 2-byte pieces of the forward shadow
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= u.off[u.n]) return;
     int t = 0;
 #pragma unroll
     for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < u.n && i >= u.off[q]) ? 1 : 0;
     const size_t j = i - u.off[t];
-    float g = 0.f;
-    for (int z = 0; z < u.sk[t]; ++z) g += u.slab[(size_t)z * u.zstride + i];
-    float w;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < u.sk[t]; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(u.slab + (size_t)z * u.zstride + i);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    float4 w = *reinterpret_cast<const float4*>(u.W[t] + j);
     if (u.adam) {
-        float m = u.Wm[t][j], v = u.Wv[t][j];
-        w = opt_step(u.adam, u.W[t][j], g, m, v, u.lr, u.beta1, u.beta2, u.eps);
-        u.Wm[t][j] = m; u.Wv[t][j] = v;
-    } else w = u.W[t][j] - u.lr * g;
-    u.W[t][j] = w;
+        float4 m = *reinterpret_cast<const float4*>(u.Wm[t] + j), v = *reinterpret_cast<const float4*>(u.Wv[t] + j);
+        w.x = opt_step(u.adam, w.x, g.x, m.x, v.x, u.lr, u.beta1, u.beta2, u.eps);
+        w.y = opt_step(u.adam, w.y, g.y, m.y, v.y, u.lr, u.beta1, u.beta2, u.eps);
+        w.z = opt_step(u.adam, w.z, g.z, m.z, v.z, u.lr, u.beta1, u.beta2, u.eps);
+        w.w = opt_step(u.adam, w.w, g.w, m.w, v.w, u.lr, u.beta1, u.beta2, u.eps);
+        *reinterpret_cast<float4*>(u.Wm[t] + j) = m; *reinterpret_cast<float4*>(u.Wv[t] + j) = v;
+    } else { w.x -= u.lr * g.x; w.y -= u.lr * g.y; w.z -= u.lr * g.z; w.w -= u.lr * g.w; }
+    *reinterpret_cast<float4*>(u.W[t] + j) = w;
     const int r = (int)(j / u.Dout[t]), c = (int)(j % u.Dout[t]);
-    static_cast<T*>(u.wf[t])[ft_off<T>(c, r, u.Din[t])] = (T)w;
-    static_cast<T*>(u.wb[t])[ft_off<T>(r, c, u.Dout[t])] = (T)w;
+    T* wf = static_cast<T*>(u.wf[t]);
+    wf[ft_off<T>(c, r, u.Din[t])] = (T)w.x; wf[ft_off<T>(c + 1, r, u.Din[t])] = (T)w.y;
+    wf[ft_off<T>(c + 2, r, u.Din[t])] = (T)w.z; wf[ft_off<T>(c + 3, r, u.Din[t])] = (T)w.w;
+    store4(static_cast<T*>(u.wb[t]) + ft_off<T>(r, c, u.Dout[t]), w.x, w.y, w.z, w.w);
 }
 
 }  // namespace
@@ -965,7 +975,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         u.adam = h->adam ? (int)h->cfg.optimizer : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
         if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
-        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off + 255) / 256 + 1)), dim3(256), 0, h->st, u);
+        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off / 4 + 255) / 256 + 1)), dim3(256), 0, h->st, u);
     }
     if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
     IHK(h, hipGetLastError());
