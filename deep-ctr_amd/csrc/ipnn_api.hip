@@ -738,6 +738,7 @@ struct ipnn_handle {
     bool prof = false;                               // HIP-event timing of the step's segments
     long long* stamps = nullptr;                     // IPNN_STAMPS=1: [2][Ba/16][16] time stamps of the strip kernels
     bool group_wgrad = true;                         // IPNN_GROUP_WGRAD=0: one launch per weight-gradient product
+    bool strip_attr = false;
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
@@ -816,11 +817,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         const size_t lds4 = E::TILE ? gemm_ft_lds<T, 4>() : 0, lds2 = E::TILE ? gemm_ft_lds<T, 2>() : 0;
         if (wg44 >= 160 && h->gemm_lds) {
             constexpr size_t ldsb = gemm_lds_bytes<T, E::TILE>();
-            static bool attr_set = false;                  // per instantiation (T, E): > 64 KiB of dynamic LDS needs the opt-in
-            if (!attr_set) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_lds<T, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-                attr_set = true;
-            }
+            // > 64 KiB of dynamic LDS needs the opt-in (opt-in path: set on every launch, a host-side call)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_lds<T, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             hipLaunchKernelGGL((k_gemm_lds<T, E>), dim3((M + 127) / 128, (N + 127) / 128, splitk), dim3(256), ldsb, h->st, A, Bm,
                                mt16, nt16, nkt_all, nkt, epi);
         } else if (wg44 >= 160)
@@ -841,11 +839,10 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const size_t strip_lds = (size_t)2 * RT * 16 * maxD * sizeof(T);
     const bool strip = h->strip && strip_lds <= 128 * 1024;
     if (strip) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_set = true;
+        if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            h->strip_attr = true;
         }
     }
     if (strip) {
