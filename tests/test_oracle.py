@@ -394,3 +394,46 @@ def test_rbm_oracle_minibatch_of_one_is_the_online_trainer():
         assert abs(ea - eb) < 1e-12
     for x, y in ((a.W, b.W), (a.visbias, b.visbias), (a.hidbias, b.hidbias), (a.weightstep, b.weightstep)):
         np.testing.assert_allclose(x, y, rtol=0, atol=1e-15)
+
+
+def test_more_golden_vectors_reproduce(golden_dir):
+    """tests/golden/make_golden_more.py fixtures (rbm_sparse, rbm_dense, snn_step, ip_l7): the oracles reproduce them."""
+    from oracle import ipnn_oracle as ipo
+    from oracle import rbm_oracle as ro
+
+    class Replay(object):
+        def __init__(self, u):
+            self.u, self.i = u, 0
+
+        def uniform(self, size=None):
+            n = int(np.prod(size)) // self.u.shape[1]
+            out = self.u[self.i:self.i + n].reshape(size)
+            self.i += n
+            return out
+    g = np.load(os.path.join(golden_dir, 'rbm_sparse.npz'))
+    st = ro.SparseRBMState(g['W0'].shape[0], g['W0'].shape[1], 32, np.random.RandomState(0))
+    st.W, st.visbias, st.hidbias = g['W0'].copy(), g['vb0'].copy(), g['hb0'].copy()
+    rp = Replay(g['unif'])
+    err = sum(ro.sparse_cd1_example(st, list(k), v, rp) for k, v in zip(g['vid'], g['vval']))
+    np.testing.assert_allclose(st.W, g['W_online'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(st.weightstep, g['ws_online'], rtol=0, atol=1e-16)
+    assert abs(err - float(g['err_online'])) < 1e-12
+    g = np.load(os.path.join(golden_dir, 'rbm_dense.npz'))
+    ds = ro.DenseRBMState(12, 8, np.random.RandomState(0))
+    ds.W, ds.visbias, ds.hidbias = g['W0'].copy(), g['vb0'].copy(), g['hb0'].copy()
+    rp = Replay(g['unif'])
+    e = [ro.dense_cd1_batch(ds, g['X'], rp), ro.dense_cd1_batch(ds, g['X'], rp)]
+    np.testing.assert_allclose(ds.W, g['W'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(e, g['err'], rtol=1e-13)
+    g = np.load(os.path.join(golden_dir, 'snn_step.npz'))
+    p = {k: (g['p0_' + k].copy() if g['p0_' + k].ndim else float(g['p0_' + k])) for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')}
+    ww, bb = g['ww0'].copy(), g['bb0'].copy()
+    res = orc.snn_train_step(p, ww, bb, g['ids'], g['y'], g['r1'].astype(float), g['r2'].astype(float), float(g['lr']), float(g['lambda1']))
+    np.testing.assert_allclose(res['p_drop'], g['p_drop'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(ww[g['touched']], g['rows_after'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(p['w1'], g['p1_w1'], rtol=0, atol=1e-15)
+    g = np.load(os.path.join(golden_dir, 'ip_l7.npz'))
+    params = {'b': float(g['b']), 'W': [g['W%d' % i] for i in range(8)], 'bias': [g['bias%d' % i] for i in range(8)]}
+    _, z1 = ipo.z1_of(g['table'], params['b'], g['ids'])
+    np.testing.assert_allclose(z1, g['z1'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(ipo.predict(params, g['table'], g['ids'], 'relu'), 1 / (1 + np.exp(-g['logits'])), rtol=1e-12)
