@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam', 'ftrl'],
+                    help='--workload ipnn only: sgd (BASELINE configs[2]), or the reference family\'s adam / ftrl (dense table pass per step)')
     ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm'],
                     help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
                          'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
@@ -425,7 +427,7 @@ def bench_ipnn(args):
     ids_np = synth.zipf_ids(NB * B, sizes, 1.1, 1234)
     y_np = (np.random.RandomState(99).uniform(size=NB * B) < 0.02).astype(np.float32)
     d = [F * K + F * (F - 1) // 2 + 1] + IP_HIDDEN + [1]
-    eng = IPNNEngine(F, K, IP_HIDDEN, 'relu', max_batch=B, precision=args.precision, lr=1e-4, keep_prob=0.5)
+    eng = IPNNEngine(F, K, IP_HIDDEN, 'relu', max_batch=B, precision=args.precision, lr=1e-4, keep_prob=0.5, optimizer=args.optimizer)
     rs = np.random.RandomState(1234)
     # uniform(-.01, .01) as python/baseline.py:140 would leave relu activations ~0 after 7 layers;
     # Glorot-scale weights keep every layer's arithmetic live (timing does not depend on the values)
@@ -464,7 +466,7 @@ def bench_ipnn(args):
         for i in range(min(args.steps, 50)):
             step(i)
         eng.sync()
-        for name in ('sort', 'ip_fwd', 'fwd', 'bwd', 'wgrad', 'ip_bwd', 'scatter', 'update'):
+        for name in ('sort', 'ip_fwd', 'fwd', 'bwd', 'wgrad', 'ip_bwd', 'scatter', 'adam_table', 'update'):
             ms = C.c_double()
             lib.ipnn_prof_get(h, name.encode(), C.byref(ms))
             seg[name] = ms.value
@@ -488,7 +490,7 @@ def bench_ipnn(args):
                 'frac': ach_step / peak, 'traffic': None, 'algorithmic_per_example': flops_ex}
     roof['step'] = {'achieved': ach_step, 'frac': ach_step / peak, 'unit': 'TFLOP/s', 'flops_per_example': flops_ex}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.optimizer == 'sgd':
         # the NumPy float64 restatement (oracle/ipnn_oracle.py, BLAS threads of the host) on the same batches, ~10 s
         from oracle import ipnn_oracle as ipo
         params = {'b': 0.0, 'W': [w.astype(np.float64) for w in Ws], 'bias': [np.zeros(d[i + 1]) for i in range(len(d) - 1)]}
@@ -516,7 +518,7 @@ def bench_ipnn(args):
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'FNN_IP_L7 train step: 16 fields, 937670 rows, k=10, z1=297, hidden 1000/800/600/400/200/100/50 relu, '
-                               'keep_prob 0.5 (mask inputs), batch %d, SGD' % B, 'per_gpu_batch': B, 'global_batch': B,
+                               'keep_prob 0.5 (mask inputs), batch %d, %s' % (B, args.optimizer.upper()), 'per_gpu_batch': B, 'global_batch': B,
                    'parallelism': 'single'},
         'train_logloss_last_step': loss.value / B, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
         'roofline': roof, 'cpu_baseline': cpu, 'kernel_ms': seg}))
