@@ -191,7 +191,7 @@ def main():
             for i in range(min(args.steps, 100)):
                 step(i)
         torch.cuda.synchronize(dev)
-        for name in ('step1', 'step2', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
+        for name in ('empty', 'step1', 'step2', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
                      'scatter', 'finalize'):
             kern_ms[name] = eng.prof_get(name)[0]
         eng.prof_enable(False)
@@ -211,6 +211,9 @@ def main():
             peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
                     'frac': ach / peak, 'traffic': None if snn else pmc_traffic(dom), 'avg_launch_ms': cand[dom],
+                    # an event-bracketed slot = kernel + the event mechanism (a back-to-back pair alone: 'event_pair_ms');
+                    # the kernel-only average of the committed rocprofv3 summary of this command is quoted beside it
+                    'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if snn else rocprof_avg_ms(dom),
                     'algorithmic_per_example': per_ex,
                     'step': {'achieved': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9,
                              'frac': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -538,6 +541,21 @@ def pmc_traffic(kernel):
     for name, v in json.load(open(files[-1])).items():
         if tag and tag in name and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
             return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+    return None
+
+
+def rocprof_avg_ms(kernel):
+    """Average duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/*_kernel_stats.csv), for comparison with the event-bracketed time measured live."""
+    import csv
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')) if 'ipnn' not in f)
+    tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
+    if not files or not tag:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if tag in r.get('Name', ''):
+            return float(r['AverageNs']) * 1e-6
     return None
 
 

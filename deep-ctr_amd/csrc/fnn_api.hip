@@ -289,6 +289,7 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
     } else h->prefetch_hits++;
     const bool have_next = h->next_ids != nullptr && !(h->next_ids == ids && h->next_B == B);
     const int nxt = h->cur ^ 1;
+    { ProfScope pe(h, "empty", h->st); }         // a back-to-back event pair: what the event mechanism itself adds to every slot
     {
         ProfScope ps(h, "step1", h->st);
         MlpArgs<T> ma = make_mlp_args<T>(h, ids, y, B, m1, m2, true, p_out);
