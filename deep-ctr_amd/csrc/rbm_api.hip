@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,6 +101,93 @@ __global__ __launch_bounds__(256) void k_rbm_sparse(const SparseArgs a)
     if (act) a.hidbias[tid] = hb;
 #pragma unroll
     for (int j = 0; j < 32; ++j) if (act && j < S) a.wstep[(size_t)j * H + tid] = ws[j];
+    if (tid == 0 && a.sq_err) *a.sq_err = err;
+}
+
+// The same pass for S = 32 (the only shape the reference's buffers admit, :388), written for instruction count -- the
+// pass is bound by the instructions one wave per SIMD issues per example, not by memory.  Lane j of every wave loads
+// id j and value j of the example; v_readlane turns them into scalars, so that the 32 row addresses are scalar
+// arithmetic (a scalar base + the thread's column), the gathers and the row stores carry no per-element branch, and
+// the value of a visible is a scalar operand of its fma.
+__global__ __launch_bounds__(256) void k_rbm_sparse32(const SparseArgs a)
+{
+    __shared__ float s_w[32][257];
+    __shared__ float s_hs[256];
+    __shared__ __align__(16) float s_vis[32];
+    __shared__ float s_e[32];
+    const int tid = threadIdx.x, lane = tid & 63, H = a.H;
+    const bool act = tid < H;
+    const int col = act ? tid : 0;                          // idle threads (H < 256) shadow column 0 and never store
+    float ws[32], hb = act ? a.hidbias[tid] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ws[j] = act ? a.wstep[(size_t)j * H + tid] : 0.f;
+    const int jj = tid >> 3, seg = tid & 7;                 // 8 lanes reduce visible jj
+    double err = 0.0;
+    for (int64_t n = 0; n < a.N; ++n) {
+        const int idv = a.vid[n * 32 + (lane & 31)];
+        const float vv = (float)a.vval[n * 32 + (lane & 31)];
+        const float u = act ? a.unif[n * H + tid] : 2.f;
+        const int my_id = __shfl(idv, jj & 31);             // wave w reduces visibles 8 w .. 8 w + 7
+        const float my_v = __shfl(vv, jj & 31);
+        const float my_vb = a.visbias[my_id];
+        int id[32]; float v[32], wc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            id[j] = __builtin_amdgcn_readlane(idv, j);
+            v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), j));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wc[j] = a.W[(size_t)id[j] * H + col];
+        float z = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z = fmaf(v[j], wc[j], z);
+        const float hid = sigm(z);                                         // hid_activate(mf=True)
+        s_hs[tid] = act ? ((u < hid) ? 1.0f : floorf(hid)) : 0.f;          // sample_hid (:371-375)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_w[j][tid] = wc[j];
+        __syncthreads();
+        {   // vis_j = sigmoid(hs . W[f_j,:] + visbias[f_j])  (mean field, :356-366)
+            float acc = 0.f;
+            for (int i = seg; i < H; i += 8) acc = fmaf(s_hs[i], s_w[jj][i], acc);
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            if (seg == 0) {
+                const float vj = sigm(acc + my_vb);
+                s_vis[jj] = vj;
+                const float d = vj - my_v;
+                s_e[jj] = d * d;
+                a.visbias[my_id] = my_vb + (my_v - vj) * a.r_vis;          // :472-484
+            }
+        }
+        __syncthreads();
+        float vis[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(s_vis + 4 * q);
+            vis[4 * q] = t4.x; vis[4 * q + 1] = t4.y; vis[4 * q + 2] = t4.z; vis[4 * q + 3] = t4.w;
+        }
+        float z2 = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z2 = fmaf(vis[j], wc[j], z2);
+        const float hid2 = sigm(z2);                                        // mean-field hiddens
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float step = ((v[j] * hid - vis[j] * hid2) - a.wcost * wc[j]) * a.r_w;   // :447-453
+            ws[j] = ws[j] * a.mom + step;                                   // :454-455
+            wc[j] = wc[j] + 2.0f * ws[j];                                   // applied twice (:461-462)
+        }
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a.W[(size_t)id[j] * H + col] = wc[j];
+        }
+        hb += (hid - hid2) * a.r_hid;                                       // :492-495
+        if (tid == 0) { float e = 0.f; for (int j = 0; j < 32; ++j) e += s_e[j]; err += (double)e; }
+        __syncthreads();          // W / visbias stores are drained (vmcnt 0) before the next example reads
+    }
+    if (act) {
+        a.hidbias[tid] = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a.wstep[(size_t)j * H + tid] = ws[j];
+    }
     if (tid == 0 && a.sq_err) *a.sq_err = err;
 }
 
@@ -435,7 +523,9 @@ int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep, con
     RCK(hipMalloc((void**)&d_err, sizeof(double)));
     SparseArgs a{W, visbias, hidbias, wstep, vid, vval, unif, N, H, S, weightcost, rate_vis, rate_hid, rate_w,
                  momentum, d_err};
-    hipLaunchKernelGGL(k_rbm_sparse, dim3(1), dim3(256), 0, st, a);
+    static const bool generic = getenv("RBM_SPARSE_GENERIC") != nullptr;       // diagnostics: the general-S kernel at S = 32
+    if (S == 32 && !generic) hipLaunchKernelGGL(k_rbm_sparse32, dim3(1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_rbm_sparse, dim3(1), dim3(256), 0, st, a);
     RCK(hipGetLastError());
     double e = 0;
     RCK(hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st));
