@@ -62,58 +62,71 @@ struct IpFwdArgs {
     int P;                      // pair products: F (F - 1) / 2 (FNN_IP_L*) or 0 (the plain FNN class, python/FNN.py:80)
     const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; const float* b;
     const uint8_t* mask; int d0; float inv_keep; int act; int D0p, ldT; int* err;
+    int skip;                   // diagnostics (IPNN_FWD_SKIP bits: 1 gather, 2 embedding store, 4 compute, 8 output stores); 0 in production
 };
 
 // gather of 16 examples' rows into an LDS tile [16][F*16]: all ids of a batch of 4 elements per thread first, then all
 // rows (two dependent round trips per batch instead of two per element)
+// STR: floats per field in the tile -- 16 (vector stores), or 17 for the forward's pair products: lanes that read slot l of
+// DIFFERENT fields then fall on different banks (with 16 all of them share two banks: a 32-way conflict per read)
+template <int STR, int NT = 256>
 __device__ __forceinline__ void ip_gather16(float* se, const int32_t* __restrict__ ids, const float* __restrict__ table16,
                                             const int64_t n_rows, const int t0, const int B, const int F, int* err)
 {
-    const int n = 16 * F * 4, FS = F * SLOT;
-    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 4) {
+    const int n = 16 * F * 4, FS = F * STR;
+    for (int e0 = threadIdx.x; e0 < n; e0 += NT * 4) {
         int64_t id[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int e = e0 + 256 * j, f = (e >> 2) % F, t = t0 + (e >> 2) / F;
+            const int e = e0 + NT * j, f = (e >> 2) % F, t = t0 + (e >> 2) / F;
             id[j] = (e < n && t < B) ? (int64_t)ids[(size_t)t * F + f] : -1;
         }
         float4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int e = e0 + 256 * j;
+            const int e = e0 + NT * j;
             if (e < n && t0 + (e >> 2) / F < B && (id[j] < 0 || id[j] >= n_rows)) { if (err) atomicOr(err, 1); id[j] = -1; }
             v[j] = id[j] >= 0 ? *reinterpret_cast<const float4*>(table16 + (size_t)id[j] * SLOT + 4 * (e & 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int e = e0 + 256 * j;
-            if (e < n) *reinterpret_cast<float4*>(se + ((e >> 2) / F) * FS + ((e >> 2) % F) * SLOT + 4 * (e & 3)) = v[j];
+            const int e = e0 + NT * j;
+            if (e < n) {
+                float* d = se + ((e >> 2) / F) * FS + ((e >> 2) % F) * STR + 4 * (e & 3);
+                if (STR == SLOT) *reinterpret_cast<float4*>(d) = v[j];
+                else { d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w; }
+            }
         }
     }
 }
 
+constexpr int IPF_NT = 512;     // 8 waves: the kernel is bound by instruction issue, two waves per SIMD overlap it
 template <typename T>
-static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T, float* __restrict__ emb)
+static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T, float* __restrict__ emb)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int EPL = Traits<T>::EPL;
     extern __shared__ __align__(16) unsigned char smem[];
-    float* se = reinterpret_cast<float*>(smem);                 // [16][F*16] raw embeddings
-    float* sa = se + 16 * a.F * SLOT;                           // [16][D0p]  a0 values
-    const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
+    constexpr int SP = SLOT + 1;                                // padded field stride of the embedding tile
+    float* se = reinterpret_cast<float*>(smem);                 // [16][F*17] raw embeddings
+    float* sa = se + 16 * a.F * SP;                             // [16][D0p]  a0 values
+    const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT, FSP = F * SP;
     const int P = a.P, CB = FS + P;
-    ip_gather16(se, a.ids, a.table16, a.n_rows, t0, B, F, a.err);
+    if (!(a.skip & 1)) ip_gather16<SP, IPF_NT>(se, a.ids, a.table16, a.n_rows, t0, B, F, a.err);
     __syncthreads();
-    if (emb)                                                    // kept for the backward of the inner products (no second gather)
-        for (int e = tid; e < 16 * FS / 4; e += 256)
-            *reinterpret_cast<float4*>(emb + (size_t)t0 * FS + 4 * e) = *reinterpret_cast<const float4*>(se + 4 * e);
+    if (emb && !(a.skip & 2))                                                    // kept for the backward of the inner products (no second gather)
+        for (int e = tid; e < 16 * FS / 4; e += IPF_NT) {
+            const int r = (4 * e) / FS, c = (4 * e) % FS;
+            const float* q = se + r * FSP + (c >> 4) * SP + (c & 15);
+            *reinterpret_cast<float4*>(emb + (size_t)t0 * FS + 4 * e) = make_float4(q[0], q[1], q[2], q[3]);
+        }
     const float bval = *a.b;
-    // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + 4 i; 4 columns at a time: their pair indices,
-    // then all 16 keep-mask bytes (one round trip), then the values
-    for (int c0 = tid & 63; c0 < a.D0p; c0 += 256) {
-        int ref[4], pi[4], pj[4];                               // ref: column in the reference's z1 order
+    // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + 8 i; 8 columns at a time: their pair indices,
+    // then all 32 keep-mask bytes (one round trip), then the values
+    for (int c0 = tid & 63; c0 < ((a.skip & 4) ? 0 : a.D0p); c0 += 512) {
+        int ref[8], pi[8], pj[8];                               // ref: column in the reference's z1 order
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const int c = c0 + 64 * k;
             ref[k] = -1; pi[k] = 0; pj[k] = 0;
             if (c < FS) { const int f = c / SLOT, l = c % SLOT; if (l < K) ref[k] = f * K + l; }
@@ -123,26 +136,26 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
                 pi[k] = i; pj[k] = i + 1 + n; ref[k] = F * K + (c - FS);
             } else if (c == CB) ref[k] = a.d0 - 1;
         }
-        float mk[4][4];
+        float mk[8][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = t0 + (tid >> 6) + 4 * i;
+            for (int i = 0; i < 2; ++i) {
+                const int t = t0 + (tid >> 6) + 8 * i;
                 mk[k][i] = (a.mask && ref[k] >= 0 && t < B) ? (float)a.mask[(size_t)t * a.d0 + ref[k]] * a.inv_keep : 1.0f;
             }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const int c = c0 + 64 * k;
             if (c >= a.D0p) break;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = (tid >> 6) + 4 * i, t = t0 + r;
+            for (int i = 0; i < 2; ++i) {
+                const int r = (tid >> 6) + 8 * i, t = t0 + r;
                 float z = 0.f;
-                if (c < FS) z = se[r * FS + c];
+                if (c < FS) z = se[r * FSP + (c >> 4) * SP + (c & 15)];
                 else if (c < CB) {
                     float s2 = 0.f;
-                    for (int l = 0; l < K; ++l) s2 = fmaf(se[r * FS + pi[k] * SLOT + l], se[r * FS + pj[k] * SLOT + l], s2);
+                    for (int l = 0; l < K; ++l) s2 = fmaf(se[r * FSP + pi[k] * SP + l], se[r * FSP + pj[k] * SP + l], s2);
                     z = s2;
                 } else if (c == CB) z = bval;
                 float v = 0.f;
@@ -156,14 +169,15 @@ static __global__ __launch_bounds__(256) void k_ip_fwd(const IpFwdArgs a, T* __r
     }
     __syncthreads();
     // F layout: this workgroup's 16 rows are one row tile; a lane-slot of a fragment = EPL consecutive columns of one row
-    for (int e = tid; e < 16 * a.D0p / EPL; e += 256) {
+    if (a.skip & 8) return;
+    for (int e = tid; e < 16 * a.D0p / EPL; e += IPF_NT) {
         const int g = e >> 4, r = e & 15;                        // column group, row
         frag fv;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) fv[x] = (T)sa[r * a.D0p + g * EPL + x];
         *reinterpret_cast<frag*>(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p)) = fv;
     }
-    for (int e = tid; e < a.D0p * 4; e += 256) {
+    for (int e = tid; e < a.D0p * 4; e += IPF_NT) {
         const int c = e >> 2, tq = e & 3;
         store4(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
                sa[(4 * tq + 2) * a.D0p + c], sa[(4 * tq + 3) * a.D0p + c]);
@@ -186,7 +200,7 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
     if (a.emb) {                                                // the raw embeddings the forward gathered
         for (int e = tid; e < 16 * FS / 4; e += 256)
             *reinterpret_cast<float4*>(se + 4 * e) = *reinterpret_cast<const float4*>(a.emb + (size_t)t0 * FS + 4 * e);
-    } else ip_gather16(se, a.ids, a.table16, a.n_rows, t0, B, F, nullptr);
+    } else ip_gather16<SLOT>(se, a.ids, a.table16, a.n_rows, t0, B, F, nullptr);
     for (int e = tid; e < 16 * a.D0p; e += 256) sd[e] = dz[(size_t)(t0 + e / a.D0p) * a.D0p + e % a.D0p];
     __syncthreads();
     for (int c = tid; c < FS; c += 256) {                        // a thread owns (field f, slot l) for all 16 examples:
@@ -572,7 +586,7 @@ struct MaskTArgs {
 };
 static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
 {
-    __shared__ uint8_t s[64][80];
+    __shared__ __align__(4) uint8_t s[64][68];          // 17 dwords per row: the 64 lanes of a byte store (one row each) spread over all banks
     int t = 0;
 #pragma unroll
     for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < a.n && (int)blockIdx.x >= a.tile0[q]) ? 1 : 0;
@@ -587,7 +601,10 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     __syncthreads();
     const int cc = threadIdx.x >> 2, q = threadIdx.x & 3;
     if (c0 + cc < a.Dp[t])
-        *reinterpret_cast<uint4*>(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT)) = *reinterpret_cast<const uint4*>(&s[cc][16 * q]);
+    {
+        const unsigned* w = reinterpret_cast<const unsigned*>(&s[cc][16 * q]);
+        *reinterpret_cast<uint4*>(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 // W_t <- W_t - lr * sum of slabs; refresh both tiled shadows.  Layer 1 rows are in slot layout.
@@ -775,7 +792,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
 {
     const int Ba = rup(B, 256), L = h->L, F = h->F, ldT = h->ldT;
     const float keep = h->cfg.keep_prob, inv_keep = 1.0f / keep;
-    const size_t lds_ip = (size_t)16 * (F * SLOT + h->Dp[0]) * sizeof(float);
+    const size_t lds_ip = (size_t)16 * (F * (SLOT + 1) + h->Dp[0]) * sizeof(float);    // k_ip_fwd pads its embedding tile
     const bool drop = train && masks;
     if (drop) for (int t = 0; t <= L; ++t) if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
     if (train) {
@@ -806,8 +823,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {
         IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
-                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag};
-        hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(256), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
+                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag,
+                     getenv("IPNN_FWD_SKIP") ? atoi(getenv("IPNN_FWD_SKIP")) : 0};
+        hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(IPF_NT), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
     }
     // one product: C [M][N] = A . B^T on fragment-tiled operands; narrow problems take smaller wave tiles
     auto gemm = [&](const T* A, const T* Bm, int M, int N, int nkt_all, int nkt, int splitk, auto epi) {
