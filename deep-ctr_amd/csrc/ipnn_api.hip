@@ -592,11 +592,20 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < a.n && (int)blockIdx.x >= a.tile0[q]) ? 1 : 0;
     const int local = (int)blockIdx.x - a.tile0[t], ntx = a.Ba / 64;
     const int t0 = (local % ntx) * 64, c0 = (local / ntx) * 64;
-    for (int i = threadIdx.x; i < 4096; i += 256) {
-        const int tt = i >> 6, cc = i & 63, ex = t0 + tt, c = c0 + cc;
+    {   // a thread's column is the same in all 16 of its elements (i = tid + 256 k): its source column once, then all
+        // 16 bytes in one round trip, then the LDS transposition
+        const int cx = threadIdx.x & 63, c = c0 + cx, d = a.d[t];
         int sc = c < a.Dp[t] ? c : -1;
-        if (t == 0) sc = sc >= 0 ? a.ref0[sc] : -1; else if (sc >= a.d[t]) sc = -1;
-        s[cc][tt] = (ex < a.B && sc >= 0) ? a.src[t][(size_t)ex * a.d[t] + sc] : (uint8_t)0;
+        if (t == 0) sc = sc >= 0 ? a.ref0[sc] : -1; else if (sc >= d) sc = -1;
+        const uint8_t* __restrict__ src = a.src[t] + (sc >= 0 ? sc : 0);
+        uint8_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int ex = t0 + (threadIdx.x >> 6) + 4 * k;
+            v[k] = (ex < a.B && sc >= 0) ? src[(size_t)ex * d] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[cx][(threadIdx.x >> 6) + 4 * k] = v[k];
     }
     __syncthreads();
     const int cc = threadIdx.x >> 2, q = threadIdx.x & 3;
