@@ -710,34 +710,50 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
         }
         return;
     }
-    // 4 consecutive elements of one row per thread (layer sizes and row lengths are multiples of 64): 16-byte slab /
-    // master / state accesses, one 8-byte piece of the backward shadow, four 2-byte pieces of the forward shadow
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= u.off[u.n]) return;
+    // A workgroup owns a 64 x 64 tile of one layer's W (row lengths are multiples of 64); a thread 4 consecutive elements
+    // of 4 rows: 16-byte slab / master / state accesses and 8-byte pieces of the backward shadow (k = column).  The forward
+    // shadow has k = row: the tile goes through LDS transposed and leaves as whole 16-byte lane slots.
+    typedef typename Traits<T>::frag frag;
+    constexpr int EPL = Traits<T>::EPL;
+    __shared__ __align__(16) T sT[64][64 + EPL];                 // [column][row], padded
+    const size_t tile = blockIdx.x;
+    if (tile * 4096 >= u.off[u.n]) return;
     int t = 0;
 #pragma unroll
-    for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < u.n && i >= u.off[q]) ? 1 : 0;
-    const size_t j = i - u.off[t];
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < u.sk[t]; ++z) {
-        const float4 v = *reinterpret_cast<const float4*>(u.slab + (size_t)z * u.zstride + i);
-        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < u.n && tile * 4096 >= u.off[q]) ? 1 : 0;
+    const int Dout = u.Dout[t], Din = u.Din[t], ntc = Dout / 64;
+    const int lt = (int)(tile - u.off[t] / 4096), r0 = (lt / ntc) * 64, c0 = (lt % ntc) * 64;
+    const int cq = (threadIdx.x & 15) * 4, sk = u.sk[t];
+    T* wb = static_cast<T*>(u.wb[t]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + (threadIdx.x >> 4) + 16 * k, c = c0 + cq;
+        const size_t j = (size_t)r * Dout + c, i = u.off[t] + j;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < sk; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(u.slab + (size_t)z * u.zstride + i);
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+        float4 w = *reinterpret_cast<const float4*>(u.W[t] + j);
+        if (u.adam) {
+            float4 m = *reinterpret_cast<const float4*>(u.Wm[t] + j), v = *reinterpret_cast<const float4*>(u.Wv[t] + j);
+            w.x = opt_step(u.adam, w.x, g.x, m.x, v.x, u.lr, u.beta1, u.beta2, u.eps);
+            w.y = opt_step(u.adam, w.y, g.y, m.y, v.y, u.lr, u.beta1, u.beta2, u.eps);
+            w.z = opt_step(u.adam, w.z, g.z, m.z, v.z, u.lr, u.beta1, u.beta2, u.eps);
+            w.w = opt_step(u.adam, w.w, g.w, m.w, v.w, u.lr, u.beta1, u.beta2, u.eps);
+            *reinterpret_cast<float4*>(u.Wm[t] + j) = m; *reinterpret_cast<float4*>(u.Wv[t] + j) = v;
+        } else { w.x -= u.lr * g.x; w.y -= u.lr * g.y; w.z -= u.lr * g.z; w.w -= u.lr * g.w; }
+        *reinterpret_cast<float4*>(u.W[t] + j) = w;
+        store4(wb + ft_off<T>(r, c, Dout), w.x, w.y, w.z, w.w);
+        const int rl = r - r0;
+        sT[cq][rl] = (T)w.x; sT[cq + 1][rl] = (T)w.y; sT[cq + 2][rl] = (T)w.z; sT[cq + 3][rl] = (T)w.w;
     }
-    float4 w = *reinterpret_cast<const float4*>(u.W[t] + j);
-    if (u.adam) {
-        float4 m = *reinterpret_cast<const float4*>(u.Wm[t] + j), v = *reinterpret_cast<const float4*>(u.Wv[t] + j);
-        w.x = opt_step(u.adam, w.x, g.x, m.x, v.x, u.lr, u.beta1, u.beta2, u.eps);
-        w.y = opt_step(u.adam, w.y, g.y, m.y, v.y, u.lr, u.beta1, u.beta2, u.eps);
-        w.z = opt_step(u.adam, w.z, g.z, m.z, v.z, u.lr, u.beta1, u.beta2, u.eps);
-        w.w = opt_step(u.adam, w.w, g.w, m.w, v.w, u.lr, u.beta1, u.beta2, u.eps);
-        *reinterpret_cast<float4*>(u.Wm[t] + j) = m; *reinterpret_cast<float4*>(u.Wv[t] + j) = v;
-    } else { w.x -= u.lr * g.x; w.y -= u.lr * g.y; w.z -= u.lr * g.z; w.w -= u.lr * g.w; }
-    *reinterpret_cast<float4*>(u.W[t] + j) = w;
-    const int r = (int)(j / u.Dout[t]), c = (int)(j % u.Dout[t]);
+    __syncthreads();
     T* wf = static_cast<T*>(u.wf[t]);
-    wf[ft_off<T>(c, r, u.Din[t])] = (T)w.x; wf[ft_off<T>(c + 1, r, u.Din[t])] = (T)w.y;
-    wf[ft_off<T>(c + 2, r, u.Din[t])] = (T)w.z; wf[ft_off<T>(c + 3, r, u.Din[t])] = (T)w.w;
-    store4(static_cast<T*>(u.wb[t]) + ft_off<T>(r, c, u.Dout[t]), w.x, w.y, w.z, w.w);
+    for (int e = threadIdx.x; e < 64 * (64 / EPL); e += 256) {      // (column, group of EPL rows): one lane slot of wf
+        const int cl = e & 63, g8 = e >> 6;
+        *reinterpret_cast<frag*>(wf + ft_off<T>(c0 + cl, r0 + g8 * EPL, Din)) = *reinterpret_cast<const frag*>(&sT[cl][g8 * EPL]);
+    }
 }
 
 }  // namespace
@@ -999,7 +1015,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         u.adam = h->adam ? (int)h->cfg.optimizer : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
         if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
-        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)((off / 4 + 255) / 256 + 1)), dim3(256), 0, h->st, u);
+        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)(off / 4096 + 1)), dim3(256), 0, h->st, u);
     }
     if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
     IHK(h, hipGetLastError());
