@@ -197,11 +197,20 @@ static __global__ __launch_bounds__(256) void k_ip_bwd(const IpBwdArgs a, const 
     float* sd = se + 16 * a.F * SLOT;                           // [16][D0p]
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT;
     const int P = a.P, CB = FS + P;
-    if (a.emb) {                                                // the raw embeddings the forward gathered
-        for (int e = tid; e < 16 * FS / 4; e += 256)
-            *reinterpret_cast<float4*>(se + 4 * e) = *reinterpret_cast<const float4*>(a.emb + (size_t)t0 * FS + 4 * e);
-    } else ip_gather16<SLOT>(se, a.ids, a.table16, a.n_rows, t0, B, F, nullptr);
-    for (int e = tid; e < 16 * a.D0p; e += 256) sd[e] = dz[(size_t)(t0 + e / a.D0p) * a.D0p + e % a.D0p];
+    // both tiles are contiguous in memory (16 consecutive rows): 16-byte pieces, eight loads in flight per thread before the
+    // first LDS store (a copy loop of one load -> one store per trip pays one memory round trip per trip)
+    auto fill = [&](float* dst, const float* __restrict__ src, const int n4) {
+        for (int e0 = tid; e0 < n4; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int e = e0 + 256 * k; v[k] = e < n4 ? *reinterpret_cast<const float4*>(src + 4 * (size_t)e) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int e = e0 + 256 * k; if (e < n4) *reinterpret_cast<float4*>(dst + 4 * e) = v[k]; }
+        }
+    };
+    if (a.emb) fill(se, a.emb + (size_t)t0 * FS, 16 * FS / 4);       // the raw embeddings the forward gathered
+    else ip_gather16<SLOT>(se, a.ids, a.table16, a.n_rows, t0, B, F, nullptr);
+    fill(sd, dz + (size_t)t0 * a.D0p, 16 * a.D0p / 4);
     __syncthreads();
     for (int c = tid; c < FS; c += 256) {                        // a thread owns (field f, slot l) for all 16 examples:
         const int f = c / SLOT, l = c % SLOT;                    // the pair index is computed once per partner field
@@ -466,7 +475,14 @@ __device__ __forceinline__ void strip_epilogue(f32x4 (&acc)[RT][4], const typena
 template <typename T> __device__ __forceinline__ void strip_load(T* dst, const T* __restrict__ src, const int nfrag16)
 {   // nfrag16 16-byte pieces, contiguous in both
     typedef typename Traits<T>::frag frag;
-    for (int i = threadIdx.x; i < nfrag16; i += blockDim.x) reinterpret_cast<frag*>(dst)[i] = reinterpret_cast<const frag*>(src)[i];
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nfrag16; i0 += nt * 4) {     // four loads in flight per thread before the first LDS store
+        frag v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + nt * k; if (i < nfrag16) v[k] = reinterpret_cast<const frag*>(src)[i]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + nt * k; if (i < nfrag16) reinterpret_cast<frag*>(dst)[i] = v[k]; }
+    }
 }
 
 #define STRIP_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
