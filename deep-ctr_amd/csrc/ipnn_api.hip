@@ -355,12 +355,14 @@ template <typename T> struct StripFwdArgs {
     const T* W[STRIP_MAXP]; int Dp[STRIP_MAXP + 1];              // W[t-1] = wf[t-1]: fragment-tiled [Dp_t][Dp_{t-1}]
     EpiIpFwd<T> ef[STRIP_MAXP]; EpiIpOut<T> eo;                  // ef[t-1], t = 1..L; eo: the output unit
     long long* dbg;                                              // IPNN_STAMPS=1 (diagnostics): s_memtime per layer, 16 per workgroup
+    int rot;                                                     // rotate the block order per workgroup (IPNN_STRIP_ROT=0: off)
 };
 template <typename T> struct StripBwdArgs {
     const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
     const T* W[STRIP_MAXP]; int Dp[STRIP_MAXP + 1];              // W[t-1] = wb[t-1]: fragment-tiled [Dp_{t-1}][Dp_t]
     EpiIpBwd<T> eb[STRIP_MAXP];                                  // eb[t-1]: product t -> delta l_{t-1}
     long long* dbg;
+    int rot;
 };
 
 // one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
@@ -491,6 +493,9 @@ constexpr int STRIP_NW = 8;                                      // waves per st
 // block in.  The weights of the NEXT block are requested before the current block's epilogue (they do not
 // depend on the strip), so the barrier between two products and the epilogue hide their L2 round trip.
 struct StripItem { int p, blk; };
+// Workgroups walk a product's column blocks in rotated order (logical block b of workgroup g is block (b + g) mod nblk), so
+// that the 16 workgroups of an XCD do not all stream the same weights -- the same L2 channels -- at the same moment.
+__device__ __forceinline__ int strip_phys(const int blk, const int nblk, const int rot) { return (blk + rot) % nblk; }
 template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd)
 {   // fwd: product p has Dp[p + 1] / 64 blocks (the output unit, p = n - 1: one); bwd: product index q = n - t, Dp[t - 1] / 64 blocks
     it.blk += STRIP_NW;
@@ -514,7 +519,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     STRIP_STAMP(0);
     StripB<T> pb;
     StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, true);
-    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, nx.blk, lane);
+    const int rot = (a.rot == 1) ? (int)(blockIdx.x >> 3) : (a.rot == 2 ? (int)blockIdx.x : 0);   // workgroups g, g + 8, ... share an XCD
+    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(nx.blk, a.Dp[nx.p + 1] / 64, rot), lane);
     // the strip of a0: row tiles RT blockIdx.x .. of an F-layout operand are contiguous
     strip_load<T>(in, a.a0 + (size_t)blockIdx.x * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
     lds_barrier();
@@ -524,14 +530,14 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
         const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
         const bool hidden = l + 1 < a.n;
         while (nx.p == l) {
-            const int blk = nx.blk;
+            const int blk = strip_phys(nx.blk, N / 64, rot);
             if (hidden) {
                 const EpiIpFwd<T> ef = a.ef[l];                 // the layer's epilogue parameters: scalar registers, loaded once
                 typename EpiIpFwd<T>::Aux ax[RT][4];
                 strip_aux<T, RT>(ax, ef, row0, blk, lane);
                 strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 nx = strip_next(a, nx, wave, true);
-                if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, nx.blk, lane);
+                if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(nx.blk, a.Dp[nx.p + 1] / 64, rot), lane);
                 strip_epilogue<T, RT>(acc, ax, ef, out, N, row0, blk, lane);
             } else {                                              // the output unit: logits, loss, delta (column 0)
                 strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
@@ -571,7 +577,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     STRIP_STAMP(0);
     StripB<T> pb;                                                 // item index q = n - t: product t = n - q
     StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false);
-    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, nx.blk, lane);
+    const int rot = (a.rot == 1) ? (int)(blockIdx.x >> 3) : (a.rot == 2 ? (int)blockIdx.x : 0);   // workgroups g, g + 8, ... share an XCD
+    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(nx.blk, a.Dp[a.n - nx.p - 1] / 64, rot), lane);
     strip_load<T>(in, a.dlast + (size_t)blockIdx.x * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
     lds_barrier();
     STRIP_STAMP(1);
@@ -579,13 +586,13 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     for (int t = a.n; t >= 1; --t) {                              // delta l_{t-1} = (delta l_t . W_t^T) * mask * act'
         const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
         while (nx.p == q) {
-            const int blk = nx.blk;
+            const int blk = strip_phys(nx.blk, N / 64, rot);
             const EpiIpBwd<T> eb = a.eb[t - 1];
             typename EpiIpBwd<T>::Aux ax[RT][4];
             strip_aux<T, RT>(ax, eb, row0, blk, lane);
             strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
             nx = strip_next(a, nx, wave, false);
-            if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, nx.blk, lane);
+            if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(nx.blk, a.Dp[a.n - nx.p - 1] / 64, rot), lane);
             strip_epilogue<T, RT>(acc, ax, eb, t > 1 ? out : nullptr, N, row0, blk, lane);
         }
         if (t > 1) lds_barrier();
@@ -915,7 +922,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        h->d[t], B};
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B};
-        sa.dbg = h->stamps;
+        sa.dbg = h->stamps; sa.rot = getenv("IPNN_STRIP_ROT") ? atoi(getenv("IPNN_STRIP_ROT")) : 1;
         hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
     } else {
     IpProf ps(h, "fwd");
@@ -943,7 +950,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        (const T*)h->aT[t - 1], drop ? h->maskT[t - 1] : nullptr, inv_keep, keep, h->cfg.act, h->d[t - 1], B,
                                        first ? h->ref0 : nullptr};
         }
-        sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr;
+        sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = getenv("IPNN_STRIP_ROT") ? atoi(getenv("IPNN_STRIP_ROT")) : 1;
         hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
     } else {
     IpProf ps(h, "bwd");
