@@ -804,6 +804,7 @@ struct ipnn_handle {
     long long* stamps = nullptr;                     // IPNN_STAMPS=1: [2][Ba/16][16] time stamps of the strip kernels
     bool group_wgrad = true;                         // IPNN_GROUP_WGRAD=0: one launch per weight-gradient product
     bool strip_attr = false;
+    int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
@@ -871,8 +872,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {
         IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
-                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag,
-                     getenv("IPNN_FWD_SKIP") ? atoi(getenv("IPNN_FWD_SKIP")) : 0};
+                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag, h->fwd_skip};
         hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(IPF_NT), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
     }
     // one product: C [M][N] = A . B^T on fragment-tiled operands; narrow problems take smaller wave tiles
@@ -922,7 +922,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        h->d[t], B};
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B};
-        sa.dbg = h->stamps; sa.rot = getenv("IPNN_STRIP_ROT") ? atoi(getenv("IPNN_STRIP_ROT")) : 1;
+        sa.dbg = h->stamps; sa.rot = h->strip_rot;
         hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
     } else {
     IpProf ps(h, "fwd");
@@ -950,7 +950,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        (const T*)h->aT[t - 1], drop ? h->maskT[t - 1] : nullptr, inv_keep, keep, h->cfg.act, h->d[t - 1], B,
                                        first ? h->ref0 : nullptr};
         }
-        sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = getenv("IPNN_STRIP_ROT") ? atoi(getenv("IPNN_STRIP_ROT")) : 1;
+        sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
         hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
     } else {
     IpProf ps(h, "bwd");
@@ -1069,6 +1069,8 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
+    if (const char* e = getenv("IPNN_FWD_SKIP")) h->fwd_skip = atoi(e);
     const char* side = getenv("IPNN_SIDE_STREAM");
     if (const char* e = getenv("IPNN_GROUP_WGRAD")) h->group_wgrad = atoi(e) != 0;
     auto fail = [&](int code) { g_ip_err = h->err; ipnn_destroy(h); return code; };
