@@ -588,6 +588,43 @@ def test_snn_step_f32_vs_oracle(built, B, kw):
     eng.close()
 
 
+def test_virtual_two_rank_dp_bag_mode(built):
+    """the SNN fine-tune shards like the FNN step.  Two bag-mode engines stand for two ranks (fnn_step_begin on
+    each half, buckets summed as the all-reduce would, fnn_step_end): dense tensors and the bag bias equal the
+    single-engine full-batch step; rows only one half touches equal the full-batch result on that rank."""
+    import torch
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(512, seed=9, dup_col=4)
+    full = make_snn_engine(ww0, bb0, p)
+    full.train_step(ids, y, r1, r2)
+    ref_dense, ref_rows, ref_bb = full.get_dense(), full.get_table(), full.get_bag_bias()
+    full.close()
+    ranks = [make_snn_engine(ww0, bb0, p) for _ in range(2)]
+    halves = [slice(0, 256), slice(256, 512)]
+    buckets = [e.step_begin(ids[h], y[h], r1, r2, b_size=512) for e, h in zip(ranks, halves)]
+    for e in ranks:
+        e.sync()
+    tot = buckets[0] + buckets[1]
+    for b in buckets:
+        b.copy_(tot)
+    torch.cuda.synchronize()
+    for e in ranks:
+        e.step_end()
+        e.sync()
+    for e in ranks:
+        d = e.get_dense()
+        for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+            scale = np.abs(d[k] - p[k].astype(np.float32)).max() + 1e-12
+            assert np.abs(d[k] - ref_dense[k]).max() <= 5e-4 * scale + 1e-7, k
+        bscale = np.abs(ref_bb - bb0).max() + 1e-12
+        assert np.abs(e.get_bag_bias() - ref_bb).max() <= 5e-4 * bscale + 1e-7
+    t0, t1 = set(np.unique(ids[halves[0]])), set(np.unique(ids[halves[1]]))
+    only0 = np.array(sorted(t0 - t1)); only1 = np.array(sorted(t1 - t0))
+    np.testing.assert_allclose(ranks[0].get_table()[only0], ref_rows[only0], rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(ranks[1].get_table()[only1], ref_rows[only1], rtol=1e-5, atol=2e-7)
+    for e in ranks:
+        e.close()
+
+
 def test_snn_step_bf16_tracks_oracle(built):
     ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(512, seed=5, dup_col=3)
     eng = make_snn_engine(ww0, bb0, p, prec='bf16')
