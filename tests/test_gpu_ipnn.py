@@ -189,3 +189,35 @@ def test_ipnn_bf16_wide_stack_tracks_oracle(built):
         cos = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
         assert cos > 0.99, (t, cos)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ipnn_random_stacks_f32_vs_oracle(built, seed):
+    """Seeded random stacks (1-8 hidden layers, widths 1..1100, batch 1..700, any activation, with and without dropout):
+    one f32 SGD step through the strip kernels and the grouped weight-gradient launch against the float64 oracle."""
+    rng = np.random.RandomState(1000 + seed)
+    L = int(rng.randint(1, 9))
+    hidden = [int(rng.choice([1, 7, 50, 63, 64, 65, 130, 300, 520, 1023, 1100])) for _ in range(L)]
+    if sum(hidden) > 2600:                                   # keep the float64 oracle quick
+        hidden = [min(h, 300) for h in hidden]
+    B = int(rng.randint(1, 701))
+    act = ['relu', 'tanh', 'sigmoid'][int(rng.randint(3))]
+    drop = bool(rng.randint(2))
+    table, ids, y, params, masks, d = problem(B, hidden, seed=seed, scale=0.05 if max(hidden) >= 200 else 0.3)
+    keep = 0.6 if drop else 1.0
+    eng = IPNNEngine(F, K, hidden, act, max_batch=max(256, B), precision='f32', lr=0.01, keep_prob=keep)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    out = eng.train_step(ids, y, masks if drop else None, want_logits=True)
+    p0 = [w.copy() for w in params['W']]
+    t0 = table.copy()
+    loss, logits, g = io.sgd_step(params, table, ids, y, act, 0.01, [m.astype(np.float64) for m in masks] if drop else None, keep)
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=5e-4, atol=5e-5)
+    assert abs(out['loss'] - loss) <= 1e-4 * max(1.0, abs(loss))
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - p0[t]).max() + 1e-12
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 3e-3 * cw + 3e-7, (t, hidden, B, act, drop)
+    touched = np.unique(ids)
+    ct = np.abs(table - t0).max() + 1e-12
+    assert np.abs(eng.get_rows(touched) - table[touched]).max() <= 3e-3 * ct + 3e-7
+    eng.close()
