@@ -87,11 +87,16 @@ def main():
     force_dp = bool(os.environ.get('FNN_BENCH_FORCE_DP'))      # exercise the DP code path with any world size
     if world > 1 or force_dp:
         import torch.distributed as dist
+        if os.environ.get('FNN_BENCH_REHEARSE'):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         if 'MASTER_ADDR' not in os.environ:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
             os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('FNN_BENCH_REHEARSE'):              # control-flow rehearsal on ONE GPU: all ranks share cuda:0, gloo collectives
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     B = args.batch
     NB = 32                                               # distinct resident batches, cycled
@@ -184,13 +189,16 @@ def main():
     # ---- per-kernel device time (HIP events on the library's own streams), same step loop
     roofline = None
     kern_ms = {}
+    # every rank runs the profiled steps (under data parallelism a step holds a collective: rank 0 alone would wait
+    # for ever); only rank 0 brackets its launches with events and reports
+    eng.prof_enable(rank == 0)
     if rank == 0:
-        eng.prof_enable(True)
         eng.prof_reset()
-        with torch.cuda.stream(eng.stream):
-            for i in range(min(args.steps, 100)):
-                step(i)
-        torch.cuda.synchronize(dev)
+    with torch.cuda.stream(eng.stream):
+        for i in range(min(args.steps, 100)):
+            step(i)
+    sync_all()
+    if rank == 0:
         for name in ('empty', 'step1', 'step2', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
                      'scatter', 'finalize'):
             kern_ms[name] = eng.prof_get(name)[0]
