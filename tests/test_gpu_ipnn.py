@@ -221,3 +221,34 @@ def test_ipnn_random_stacks_f32_vs_oracle(built, seed):
     ct = np.abs(table - t0).max() + 1e-12
     assert np.abs(eng.get_rows(touched) - table[touched]).max() <= 3e-3 * ct + 3e-7
     eng.close()
+
+
+def test_ipnn_many_steps_track_oracle(built):
+    """Twelve consecutive SGD steps with fresh dropout masks and different batches (side-stream work of one step overlaps
+    the next step's start): parameters and touched rows still follow the float64 oracle."""
+    hidden = [130, 70, 40]
+    table, ids0, y0, params, masks0, d = problem(200, hidden, seed=31, scale=0.1)
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=256, precision='f32', lr=0.02, keep_prob=0.7)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    p0 = [w.copy() for w in params['W']]
+    t0 = table.copy()
+    rng = np.random.RandomState(77)
+    sizes = synth.field_sizes_tiny(600)
+    touched = set()
+    for step in range(12):
+        B = int(rng.randint(60, 201))
+        ids = synth.zipf_ids(B, sizes, 1.1, 100 + step)
+        y = (rng.uniform(size=B) < 0.3).astype(np.float64)
+        masks = [(rng.uniform(size=(B, d[t])) < 0.7).astype(np.uint8) for t in range(len(hidden) + 1)]
+        out = eng.train_step(ids, y, masks, want_logits=(step == 11))
+        loss, logits, _ = io.sgd_step(params, table, ids, y, 'relu', 0.02, [m.astype(np.float64) for m in masks], 0.7)
+        touched |= set(np.unique(ids).tolist())
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=2e-3, atol=2e-4)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - p0[t]).max()
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 5e-3 * cw + 1e-6, t
+    tr = np.array(sorted(touched))
+    ct = np.abs(table - t0).max()
+    assert np.abs(eng.get_rows(tr) - table[tr]).max() <= 5e-3 * ct + 1e-6
+    eng.close()
