@@ -412,7 +412,7 @@ static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A,
 // problem q owns workgroups wg0[q] .. wg0[q+1]-1, laid out (x fastest, then y, then the K split).
 constexpr int GEMM_GROUP_MAX = 9;
 struct GemmGroupProb { const void* A; const void* B; float* out; int mt16, nt16, nkt_all, nkt, ldo, gx, gy; };
-struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int wg0[GEMM_GROUP_MAX + 1]; int n; size_t zstride; };
+struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int wg0[GEMM_GROUP_MAX + 1]; int n; size_t zstride; int xcd; };
 
 template <typename T, int TM, int TN>
 static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g)
@@ -421,7 +421,14 @@ static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g
 #pragma unroll
     for (int i = 1; i < GEMM_GROUP_MAX; ++i) q += (i < g.n && (int)blockIdx.x >= g.wg0[i]) ? 1 : 0;
     const GemmGroupProb& pr = g.p[q];
-    const int local = (int)blockIdx.x - g.wg0[q];
+    int local = (int)blockIdx.x - g.wg0[q];
+    if (g.xcd) {
+        // XCD-aware order inside a problem: hardware workgroup ids that differ by a multiple of 8 share an XCD; the n tiles of
+        // the problem are dealt so that each of those 8 classes owns one contiguous run of logical tiles (x fastest: a run
+        // shares its B panel and a few A panels).  Across problems the launch order (round robin) keeps the XCDs balanced.
+        const int n = g.wg0[q + 1] - g.wg0[q], cls = local & 7, k = local >> 3, qd = n >> 3, rm = n & 7;
+        local = (cls < rm ? cls * (qd + 1) : rm * (qd + 1) + (cls - rm) * qd) + k;
+    }
     const int bx = local % pr.gx, by = (local / pr.gx) % pr.gy, bz = local / (pr.gx * pr.gy);
     const EpiF32 e{pr.out, pr.ldo, g.zstride};
     gemm_ft_body<T, TM, TN, EpiF32>(static_cast<const T*>(pr.A), static_cast<const T*>(pr.B), pr.mt16, pr.nt16, pr.nkt_all, pr.nkt, e, bx, by, bz);

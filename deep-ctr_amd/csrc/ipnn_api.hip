@@ -804,6 +804,7 @@ struct ipnn_handle {
     long long* stamps = nullptr;                     // IPNN_STAMPS=1: [2][Ba/16][16] time stamps of the strip kernels
     bool group_wgrad = true;                         // IPNN_GROUP_WGRAD=0: one launch per weight-gradient product
     bool strip_attr = false;
+    int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
@@ -1012,7 +1013,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                 pr.nkt_all = ldT / KS; pr.nkt = Ba / KS / sk; pr.ldo = N; pr.gx = (M + 127) / 128; pr.gy = (N + 127) / 128;
                 g.wg0[i] = wg; wg += pr.gx * pr.gy * sk;
             }
-            g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride;
+            g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride; g.xcd = h->group_xcd;
             hipLaunchKernelGGL((k_gemm_group<T, 4, 4>), dim3(wg), dim3(256), 0, h->st, g);
         } else {
         size_t off = 0;
@@ -1070,6 +1071,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
+    if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
     if (const char* e = getenv("IPNN_FWD_SKIP")) h->fwd_skip = atoi(e);
     const char* side = getenv("IPNN_SIDE_STREAM");
     if (const char* e = getenv("IPNN_GROUP_WGRAD")) h->group_wgrad = atoi(e) != 0;
