@@ -252,3 +252,26 @@ def test_ipnn_many_steps_track_oracle(built):
     ct = np.abs(table - t0).max()
     assert np.abs(eng.get_rows(tr) - table[tr]).max() <= 5e-3 * ct + 1e-6
     eng.close()
+
+
+def test_ipnn_l7_benchmark_shape_bf16(built):
+    """The benchmark configuration itself (BASELINE configs[2]: hidden 1000/800/600/400/200/100/50, batch 4096, bf16,
+    keep_prob 0.5): one step against the float64 oracle -- logits within 5e-2, loss within 2 %, every weight update
+    pointing the oracle's way (cosine > 0.98; bf16 operands, f32 accumulation)."""
+    hidden = [1000, 800, 600, 400, 200, 100, 50]
+    B = 4096
+    table, ids, y, params, masks, d = problem(B, hidden, seed=5, n_rows=3000, scale=0.06)
+    masks = [(np.random.RandomState(40 + t).uniform(size=(B, d[t])) < 0.5).astype(np.uint8) for t in range(len(hidden) + 1)]
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='bf16', lr=1e-3, keep_prob=0.5)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    out = eng.train_step(ids, y, masks, want_logits=True)
+    p0 = [w.copy() for w in params['W']]
+    loss, logits, g = io.sgd_step(params, table, ids, y, 'relu', 1e-3, [m.astype(np.float64) for m in masks], 0.5)
+    assert np.abs(out['logits'].cpu().numpy() - logits).max() < 5e-2
+    assert abs(out['loss'] - loss) <= 2e-2 * abs(loss)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        du, dv = (Ws[t] - p0[t]).ravel(), (params['W'][t] - p0[t]).ravel()
+        cos = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
+        assert cos > 0.98, (t, cos)
+    eng.close()
