@@ -494,7 +494,7 @@ def bench_ipnn(args):
         kname = {'fwd': 'k_ip_strip_fwd (deep stack forward, one launch)', 'bwd': 'k_ip_strip_bwd (deep stack backward-data, one launch)',
                  'wgrad': 'k_gemm_group (all weight gradients, one launch)'}[dom]
         roof = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak, 'traffic': None, 'avg_launch_ms': seg[dom], 'algorithmic_per_example': fl[dom]}
+                'frac': ach / peak, 'traffic': pmc_traffic_ipnn(dom), 'avg_launch_ms': seg[dom], 'algorithmic_per_example': fl[dom]}
     ach_step = flops_ex * B / (ms_per_step * 1e-3) / 1e12
     if roof is None:
         roof = {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach_step, 'peak': peak, 'unit': 'TFLOP/s',
@@ -548,6 +548,20 @@ def pmc_traffic(kernel):
     tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
     for name, v in json.load(open(files[-1])).items():
         if tag and tag in name and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
+            return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+    return None
+
+
+def pmc_traffic_ipnn(seg):
+    """HBM-side bytes per launch of the inner-product family's dominant kernel, from the newest committed PMC passes
+    (profiles/*_pmc_traffic_ipnn.json; FETCH_SIZE doubled as in pmc_traffic)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_ipnn.json')))
+    tag = {'fwd': 'k_ip_strip_fwd', 'bwd': 'k_ip_strip_bwd', 'wgrad': 'k_gemm_group'}.get(seg)
+    if not files or not tag:
+        return None
+    for name, v in json.load(open(files[-1])).items():
+        if tag in name and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
             return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
     return None
 
