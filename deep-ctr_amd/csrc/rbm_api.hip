@@ -293,21 +293,37 @@ __global__ __launch_bounds__(256) void k_rbm_apply(float* __restrict__ W, float*
     }
 }
 
-__global__ __launch_bounds__(256) void k_rbm_batch_tail(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ part_w,
-                                                        const float* __restrict__ part_h, const double* __restrict__ part_e, int nwg, int M,
-                                                        int H, int S, float mom, float r_hid, double* __restrict__ err_acc)
+// 64 elements x 16 groups of workgroup partials per block: a thread sums every 16th partial of its element (eight loads
+// in flight at a time), the 16 group sums meet in LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ part_w,
+                                                         const float* __restrict__ part_h, const double* __restrict__ part_e, int nwg, int M,
+                                                         int H, int S, float mom, float r_hid, double* __restrict__ err_acc)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;              // element of [S][H], then of [H]
-    if (i < S * H) {
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += part_w[(size_t)w * S * H + i];
-        wstep[i] = mom * wstep[i] + s / (float)M;
-    } else if (i < S * H + H) {
-        const int hcol = i - S * H;
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += part_h[(size_t)w * H + hcol];
-        hidbias[hcol] += r_hid * s;
-    } else if (i == S * H + H) {
+    __shared__ float s_p[16][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + el, nW = S * H, n = nW + H;
+    float s = 0.f;
+    if (i < n) {
+        const float* base = i < nW ? part_w + i : part_h + (i - nW);
+        const size_t stride = i < nW ? (size_t)nW : (size_t)H;
+        for (int w0 = grp; w0 < nwg; w0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int w = w0 + 16 * k; v[k] = w < nwg ? base[(size_t)w * stride] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+    }
+    s_p[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += s_p[g][el];
+        if (i < nW) wstep[i] = mom * wstep[i] + t / (float)M;
+        else hidbias[i - nW] += r_hid * t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         double e = 0.0;
         for (int w = 0; w < nwg; ++w) e += part_e[w];
         *err_acc += e;
@@ -555,7 +571,7 @@ int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hi
                     momentum, part_w, part_h, part_e};
         hipLaunchKernelGGL(k_rbm_batch, dim3(nwg), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
-        hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 1 + 255) / 256)), dim3(256), 0, st, wstep, hidbias, part_w, part_h,
+        hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 63) / 64)), dim3(1024), 0, st, wstep, hidbias, part_w, part_h,
                            part_e, nwg, m, H, S, momentum, rate_hid, d_err);
     }
     RCK(hipGetLastError());
