@@ -90,7 +90,7 @@ __global__ void k_fm_tail(float* b, const float* gb_part, int n, float lr, float
     __shared__ float sl[256];
     if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s += gb_part[i]; *b = *b * (1.0f - lr * lambda) - lr * s; }
     float v = 0.f;
-    for (int i = threadIdx.x; i < Ba; i += 256) v += loss_t[i];
+    v = strided_sum256(loss_t, Ba);
     sl[threadIdx.x] = v; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) *loss_out = sl[0] * lscale;

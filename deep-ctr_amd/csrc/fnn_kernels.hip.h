@@ -73,6 +73,20 @@ template <typename T> __device__ inline const T* ft_frag(const T* base, int rt, 
     return base + ((size_t)(rt * nkt + kt) * 64 + lane) * Traits<T>::EPL;
 }
 
+// sum of x[tid], x[tid + 256], ... (< n) in that order, with 8 loads in flight at a time: a plain `v += x[i]` loop pays one
+// memory round trip per element
+__device__ inline float strided_sum256(const float* __restrict__ x, const int n) {
+    float v = 0.f;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = i0 + 256 * k; t[k] = i < n ? x[i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += t[k];
+    }
+    return v;
+}
+
 __device__ inline void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
@@ -1143,7 +1157,7 @@ static __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__
     if (blockIdx.x == gridDim.x - 1) {                       // loss: fixed-shape tree
         __shared__ float s_l[256];
         float v = 0.f;
-        for (int i = threadIdx.x; i < Ba; i += 256) v += loss_t[i];
+        v = strided_sum256(loss_t, Ba);
         s_l[threadIdx.x] = v;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {

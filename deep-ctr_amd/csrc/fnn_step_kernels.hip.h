@@ -212,7 +212,7 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
     if (b == ta.nblk_red - 1) {                                // loss: fixed-shape tree
         float* s_l = reinterpret_cast<float*>(&s_sum[0][0]);
         float v = 0.f;
-        for (int i = threadIdx.x; i < ta.Ba; i += 256) v += ta.loss_t[i];
+        v = strided_sum256(ta.loss_t, ta.Ba);
         s_l[threadIdx.x] = v;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {

@@ -719,8 +719,8 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     if (blockIdx.x == gridDim.x - 1) {               // scalar tail: b and the loss, fixed-shape trees
         __shared__ float sl[256], sg[256];
         float v = 0.f, g = 0.f;
-        for (int i = threadIdx.x; i < u.Ba; i += 256) v += u.loss_t[i];
-        for (int i = threadIdx.x; i < u.ngb; i += 256) g += u.gb_part[i];
+        v = strided_sum256(u.loss_t, u.Ba);
+        g = strided_sum256(u.gb_part, u.ngb);
         sl[threadIdx.x] = v; sg[threadIdx.x] = g; __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sg[threadIdx.x] += sg[threadIdx.x + o]; }
