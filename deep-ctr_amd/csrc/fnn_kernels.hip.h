@@ -1413,11 +1413,20 @@ __device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
     if (chunk >= sa.F * NQ) return;
     const int f = chunk / NQ, qc = chunk % NQ, base = qc * WCH;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    // the records of the NEXT batch of 8 entries are requested together with the gradients / old rows of the current one:
+    // one memory round trip per batch instead of two (records, then what they point at)
+    int4 rn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rn[j] = sa.rec[(size_t)f * N2 + base + j];
     for (int sb = 0; sb < WCH; sb += 8) {
         int4 r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = sa.rec[(size_t)f * N2 + base + sb + j];
+        for (int j = 0; j < 8; ++j) r[j] = rn[j];
         if (r[0].x < 0) break;                               // invalid keys sort to the end
+        if (sb + 8 < WCH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rn[j] = sa.rec[(size_t)f * N2 + base + sb + 8 + j];
+        }
         float4 g[8], wold[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
