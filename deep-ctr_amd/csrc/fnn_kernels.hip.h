@@ -735,6 +735,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         // ---- P0 (bag): x = sigmoid(sum_f ww0[id_f] + bb0).  ids of the strip first (one per thread),
         // then every thread sums the 16-byte quarter-columns it owns over the F rows: F independent
         // loads in flight per item, rw/4 items per example.
+        constexpr int BAGL = 16;             // row loads in flight per item (all 16 fields of an example at once)
         const int rw = a.rw, nq = rw >> 2;
         for (int e = tid; e < 16 * F; e += 256) {
             const int t = t0 + e / F;
@@ -749,16 +750,16 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int e = tid; e < 16 * nq; e += 256) {
             const int r = e / nq, c4 = e % nq;
             float4 acc = *reinterpret_cast<const float4*>(a.bb0 + 4 * c4);
-            for (int f0 = 0; f0 < F; f0 += 8) {
-                float4 v[8]; float w[8];
+            for (int f0 = 0; f0 < F; f0 += BAGL) {
+                float4 v[BAGL]; float w[BAGL];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < BAGL; ++u) {
                     const int id = (f0 + u < F) ? sids[r * F + f0 + u] : -1;
                     w[u] = id >= 0 ? 1.0f : 0.0f;
                     v[u] = *reinterpret_cast<const float4*>(a.table16 + (size_t)(id < 0 ? 0 : id) * rw + 4 * c4);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < BAGL; ++u) {
                     acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
                     acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
                 }
