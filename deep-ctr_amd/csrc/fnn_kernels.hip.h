@@ -1465,10 +1465,22 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
         const int4 ow = sa.owners[o];                      // {f, s, e, row}
         const int q0 = ow.y / WCH, q1 = (ow.z - 1) / WCH;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        // the row the segment updates is requested with the partial sums, not after them (one round trip less)
+        float4* p = reinterpret_cast<float4*>(sa.table16 + (size_t)ow.w * rw + 4 * q);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp == 0) w = *p;
         if (grp < ngrp) {
-            for (int qq = q0 + grp; qq <= q1; qq += ngrp) {
-                const double* pp = sa.part + (((size_t)ow.x * NQ + qq) * 2 + (qq == q0 ? 1 : 0)) * rw + 4 * q;
-                a0 += pp[0]; a1 += pp[1]; a2 += pp[2]; a3 += pp[3];
+            for (int qq0 = q0 + grp; qq0 <= q1; qq0 += 4 * ngrp) {           // four chunks' partials in flight at a time
+                double v[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int qq = qq0 + k * ngrp;
+                    const double* pp = sa.part + (((size_t)ow.x * NQ + (qq <= q1 ? qq : q1)) * 2 + (qq == q0 ? 1 : 0)) * rw + 4 * q;
+                    const bool on = qq <= q1;
+                    v[k][0] = on ? pp[0] : 0.0; v[k][1] = on ? pp[1] : 0.0; v[k][2] = on ? pp[2] : 0.0; v[k][3] = on ? pp[3] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a0 += v[k][0]; a1 += v[k][1]; a2 += v[k][2]; a3 += v[k][3]; }
             }
             double* d = s_w + ((size_t)grp * nq + q) * 4;
             d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
@@ -1480,8 +1492,6 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
                 const double* d = s_w + ((size_t)gI * nq + q) * 4;
                 t0 += d[0]; t1 += d[1]; t2 += d[2]; t3 += d[3];
             }
-            float4* p = reinterpret_cast<float4*>(sa.table16 + (size_t)ow.w * rw + 4 * q);
-            const float4 w = *p;
             *p = make_float4((float)(w.x - sa.lr * t0), (float)(w.y - sa.lr * t1), (float)(w.z - sa.lr * t2),
                              (float)(w.w - sa.lr * t3));
         }
