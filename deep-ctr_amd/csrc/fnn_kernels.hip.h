@@ -1377,16 +1377,27 @@ __device__ __forceinline__ void scat2_body(const ScatArgs& sa, const int blk, co
         const int4 ow = owners[o];                         // {f, s, e, row}
         const int q0 = ow.y >> 4, q1 = (ow.z - 1) >> 4;
         double sum = 0.0;
-        for (int q = q0 + grp; q <= q1; q += 16)
-            sum += part[(((size_t)ow.x * NQ + q) * 2 + (q == q0 ? 1 : 0)) * SLOT + l];
+        // the row and its decay factor are requested with the partial sums, not after them (one round trip less)
+        float* p = table16 + (size_t)ow.w * SLOT + l;
+        float wold = 0.f; double cdec = 0.0;
+        if (grp == 0 && l < K) { wold = *p; cdec = cpow[ow.z - ow.y]; }
+        for (int qb = q0 + grp; qb <= q1; qb += 64) {            // four chunks' partials in flight at a time
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = qb + 16 * k;
+                v[k] = q <= q1 ? part[(((size_t)ow.x * NQ + q) * 2 + (q == q0 ? 1 : 0)) * SLOT + l] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += v[k];
+        }
         s_sum[grp][l] = sum;
         __syncthreads();
         if (grp == 0 && l < K) {
             double tot = 0.0;
 #pragma unroll
             for (int gI = 0; gI < 16; ++gI) tot += s_sum[gI][l];
-            float* p = table16 + (size_t)ow.w * SLOT + l;
-            *p = (float)((double)*p * cpow[ow.z - ow.y] - lr * tot);
+            *p = (float)((double)wold * cdec - lr * tot);
         }
         __syncthreads();
     }
