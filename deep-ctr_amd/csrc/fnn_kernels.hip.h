@@ -1444,7 +1444,11 @@ __device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
         for (int j = 0; j < 8; ++j) {
             const bool live = r[j].x >= 0;
             g[j] = *reinterpret_cast<const float4*>(sa.gxp + (size_t)(live ? r[j].y : 0) * sa.K1p + 4 * q);
-            wold[j] = *reinterpret_cast<const float4*>(sa.table16 + (size_t)(live ? r[j].x : 0) * rw + 4 * q);
+            // the old row is read only where it is written: at the last entry of a segment that lies inside this chunk
+            const int pos = base + sb + j;
+            const bool need = live && pos + 1 == r[j].w && r[j].z >= base;
+            // (branch-free: entries that do not need it read row 0, which stays in cache)
+            wold[j] = *reinterpret_cast<const float4*>(sa.table16 + (size_t)(need ? r[j].x : 0) * rw + 4 * q);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
