@@ -232,6 +232,29 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not snn:
         cpu = cpu_baseline(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
         cpu_vec = cpu_baseline_vectorised(rows, ids_np, y_np, m1_np, m2_np, p0, B, args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and snn:
+        # the float64 restatement of python/SNN_RBM.py:238-291 (oracle.fnn_oracle.snn_train_step: NumPy bag + MLP, the
+        # reference's per-example Python loop for the row updates) on the same table / ids, bounded sample
+        from oracle import fnn_oracle as orc
+        ww64 = (np.random.default_rng(1234).standard_normal((sum(sizes), H0), dtype=np.float32) * np.float32(0.05)).astype(np.float64)
+        bb64 = np.zeros(H0)
+        ut.seed_global(1234)
+        w1s, _ = ut.init_weight(H0, H1, 'sigmoid'); w2s, _ = ut.init_weight(H1, H2, 'sigmoid')
+        pc = {'w1': np.array(w1s, np.float64), 'b1': np.zeros(H1), 'w2': np.array(w2s, np.float64), 'b2': np.zeros(H2), 'w3': np.zeros(H2), 'b3': 0.0}
+        n, t0c = 0, time.perf_counter()
+        while True:
+            b = n % NB
+            sl = slice(b * B, (b + 1) * B)
+            orc.snn_train_step(pc, ww64, bb64, ids_np[sl], y_np[sl].astype(np.float64), m1_np[b].astype(np.float64), m2_np[b].astype(np.float64),
+                               0.001, 0.0)
+            n += 1
+            el = time.perf_counter() - t0c
+            if el >= args.cpu_seconds or n >= 200:
+                break
+        cpu = {'value': n * B / el, 'unit': 'examples/sec', 'cores': 1, 'kind': 'port',
+               'sample': '%d steps of batch %d on the same table/ids (oracle.fnn_oracle.snn_train_step: NumPy float64, per-example row '
+                         'updates in the interpreter as in the reference; host has %d cores)' % (n, B, os.cpu_count())}
+        del ww64
 
     if rank == 0:
         out = {
