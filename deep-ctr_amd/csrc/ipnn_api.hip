@@ -804,6 +804,7 @@ struct ipnn_handle {
     long long* stamps = nullptr;                     // IPNN_STAMPS=1: [2][Ba/16][16] time stamps of the strip kernels
     bool group_wgrad = true;                         // IPNN_GROUP_WGRAD=0: one launch per weight-gradient product
     bool strip_attr = false;
+    int mask_side = 0;                               // IPNN_MASK_SIDE=1: the mask transposition on the side stream
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
@@ -858,8 +859,10 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                 tiles += (Ba / 64) * (h->Dp[t] / 64);
             }
             ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
-            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, ss, ma);
-            if (h->st2) IHK(h, hipEventRecord(h->ev_mask, h->st2));
+            // on the MAIN stream by default: a cross-stream event on the way into the first strip kernel costs more (10-20 us of
+            // wait resolution, measured on the kernel trace) than the 10 us the transposition takes in line
+            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->mask_side ? ss : h->st, ma);
+            if (h->st2 && h->mask_side) IHK(h, hipEventRecord(h->ev_mask, h->st2));
         }
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
         if (h->key64) {
@@ -898,7 +901,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL((k_gemm_ft<T, 2, 2, E>), dim3((M + 63) / 64, (N + 63) / 64, splitk), dim3(256), lds2, h->st, A, Bm,
                                mt16, nt16, nkt_all, nkt, epi);
     };
-    if (drop && h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_mask, 0));     // the strips / GEMMs read the transposed masks
+    if (drop && h->st2 && h->mask_side) IHK(h, hipStreamWaitEvent(h->st, h->ev_mask, 0));     // the strips / GEMMs read the transposed masks
     constexpr int KS = Traits<T>::KS;
     int maxD = 0;
     for (int t = 0; t <= L + 1; ++t) maxD = std::max(maxD, h->Dp[t]);
@@ -1072,6 +1075,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
+    if (const char* e = getenv("IPNN_MASK_SIDE")) h->mask_side = atoi(e);
     if (const char* e = getenv("IPNN_FWD_SKIP")) h->fwd_skip = atoi(e);
     const char* side = getenv("IPNN_SIDE_STREAM");
     if (const char* e = getenv("IPNN_GROUP_WGRAD")) h->group_wgrad = atoi(e) != 0;
