@@ -713,24 +713,35 @@ struct IpUpdArgs {
     float beta1, beta2, eps; float* Wm[IPNN_MAX_HIDDEN + 1]; float* Wv[IPNN_MAX_HIDDEN + 1]; float* bmv;
 };
 
+// The scalar b of z1 (python/FNN_IP_L7.py:104-114): its gradient is the sum of the per-workgroup partials of k_ip_bwd.  A launch
+// of its own on the side stream, right behind k_ip_bwd, so that the dense update on the main stream depends on nothing there.
+static __global__ __launch_bounds__(256) void k_ip_b_update(float* __restrict__ b, const float* __restrict__ gb_part, int ngb, int opt,
+                                                            float* __restrict__ bmv, float lr, float beta1, float beta2, float eps)
+{
+    __shared__ float sg[256];
+    sg[threadIdx.x] = strided_sum256(gb_part, ngb);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sg[threadIdx.x] += sg[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (opt) *b = opt_step(opt, *b, sg[0], bmv[0], bmv[1], lr, beta1, beta2, eps);
+        else *b -= lr * sg[0];
+    }
+}
+
 template <typename T>
 static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
 {
-    if (blockIdx.x == gridDim.x - 1) {               // scalar tail: b and the loss, fixed-shape trees
-        __shared__ float sl[256], sg[256];
-        float v = 0.f, g = 0.f;
-        v = strided_sum256(u.loss_t, u.Ba);
-        g = strided_sum256(u.gb_part, u.ngb);
-        sl[threadIdx.x] = v; sg[threadIdx.x] = g; __syncthreads();
+    if (blockIdx.x == gridDim.x - 1) {               // scalar tail: the loss, a fixed-shape tree (b: k_ip_b_update)
+        __shared__ float sl[256];
+        sl[threadIdx.x] = strided_sum256(u.loss_t, u.Ba); __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sg[threadIdx.x] += sg[threadIdx.x + o]; }
+            if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            *u.loss_sum = sl[0];
-            if (u.adam) *u.b = opt_step(u.adam, *u.b, sg[0], u.bmv[0], u.bmv[1], u.lr, u.beta1, u.beta2, u.eps);
-            else *u.b -= u.lr * sg[0];
-        }
+        if (threadIdx.x == 0) *u.loss_sum = sl[0];
         return;
     }
     // A workgroup owns a 64 x 64 tile of one layer's W (row lengths are multiples of 64); a thread 4 consecutive elements
@@ -972,12 +983,19 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {
         hipStream_t ss = h->st2 ? h->st2 : h->st;
         if (h->st2) { IHK(h, hipEventRecord(h->ev_bwd, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_bwd, 0)); }
+        if (h->adam) {
+            h->adam_t += 1;
+            if (!h->ftrl)
+                lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
+                                  (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
+        }
         {
             IpProf ps(h, "ip_bwd", ss);
             IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0], h->emb};
             hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, ss, ba, h->dz0, h->gxp, h->gb_part);
+            hipLaunchKernelGGL(k_ip_b_update, dim3(1), dim3(256), 0, ss, h->b, h->gb_part, Ba / 16, h->adam ? (int)h->cfg.optimizer : 0, h->bmv,
+                               lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps);
         }
-        if (h->st2) IHK(h, hipEventRecord(h->ev_ipb, h->st2));                 // gb_part: the update launch reads it
         {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
             IpProf ps(h, "scatter", ss);
             // Adam / FTRL: the same sorted sums land in the (zero) gradient table instead: G[row] = 0 * 1 - (-1) * sum
@@ -987,10 +1005,6 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, ss, sa);
         }
         if (h->adam) {
-            h->adam_t += 1;
-            if (!h->ftrl)
-                lr_step = (float)((double)h->cfg.lr * std::sqrt(1.0 - std::pow((double)h->cfg.adam_beta2, (double)h->adam_t)) /
-                                  (1.0 - std::pow((double)h->cfg.adam_beta1, (double)h->adam_t)));
             IpProf ps(h, "adam_table", ss);
             const size_t n = (size_t)h->n_rows * SLOT;
             hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ss, h->table16, h->tm, h->tv, h->tG, n,
@@ -1028,7 +1042,6 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         }
         }
     }
-    if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_ipb, 0));
     {
         IpProf ps(h, "update");
         size_t off = 0;
