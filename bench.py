@@ -154,9 +154,13 @@ def main():
         else:
             rc = lib.fnn_step_begin(*a, None, None, _capi.FNN_MEM_DEVICE)
             if rc == 0:
-                work = dist.all_reduce(bucket, async_op=True)    # RCCL, ordered after the dense half
-                rc = lib.fnn_step_scatter(h)                     # sparse half overlaps the collective
-                work.wait()
+                if os.environ.get('FNN_BENCH_DP_SYNC'):           # experiment: no overlap, the collective in line
+                    dist.all_reduce(bucket)
+                    rc = lib.fnn_step_scatter(h)
+                else:
+                    work = dist.all_reduce(bucket, async_op=True)    # RCCL, ordered after the dense half
+                    rc = lib.fnn_step_scatter(h)                     # sparse half overlaps the collective
+                    work.wait()
                 if rc == 0:
                     rc = lib.fnn_step_end(h, None)
         if rc != 0:
