@@ -804,7 +804,10 @@ struct ipnn_handle {
     std::vector<float*> W; std::vector<void*> wf, wb;           // W[t], t = 1..L+1 (index t-1)
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
     std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
-    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr, ev_bwd = nullptr, ev_ipb = nullptr;   // side stream for the id grouping (IPNN_SIDE_STREAM=0: inline)
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr, ev_bwd = nullptr;
+    // side stream (IPNN_SIDE_STREAM=0: everything in line): the id grouping from the start of the step; the inner-product backward,
+    // the scalar b and the sparse-row update beside the weight gradients.  ev_fork / ev_bwd: main -> side; ev_join: side -> main at
+    // the end of the step (ev_mask only with IPNN_MASK_SIDE=1)
     float* emb = nullptr;                            // [ldT][F*16] raw embeddings of the step's examples (forward -> backward)
     float *dz0 = nullptr, *gxp = nullptr, *gb_part = nullptr, *loss_t = nullptr, *loss_dev = nullptr, *slab = nullptr;
     int* ref0 = nullptr; int* err_flag = nullptr;
@@ -858,8 +861,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const bool drop = train && masks;
     if (drop) for (int t = 0; t <= L; ++t) if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
     if (train) {
-        // beside the stack, on the side stream: the transposed keep-masks (inputs of the step; needed from the first
-        // product on) and the grouping of the batch's ids for the sparse-row update (needed by the scatter)
+        // beside the stack, on the side stream: the grouping of the batch's ids for the sparse-row update (needed by the scatter);
+        // the transposed keep-masks (needed from the first product on) go first on the main stream
         hipStream_t ss = h->st2 ? h->st2 : h->st;
         if (h->st2) { IHK(h, hipEventRecord(h->ev_fork, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_fork, 0)); }
         if (drop) {   // keep-masks of all layers -> transposed, tiled, zero padded, slot-ordered for layer 0
@@ -1100,7 +1103,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
         IK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         IK(hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming));
-        IK(hipEventCreateWithFlags(&h->ev_bwd, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_ipb, hipEventDisableTiming));
+        IK(hipEventCreateWithFlags(&h->ev_bwd, hipEventDisableTiming));
     }
     h->d.resize(h->L + 2); h->Dp.resize(h->L + 2);
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
@@ -1188,7 +1191,6 @@ int ipnn_destroy(ipnn_handle* h)
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mask) hipEventDestroy(h->ev_mask);
     if (h->ev_bwd) hipEventDestroy(h->ev_bwd);
-    if (h->ev_ipb) hipEventDestroy(h->ev_ipb);
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
