@@ -222,7 +222,7 @@ def main():
             ach = per_ex * B / t_s / 1e12
             peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                    'frac': ach / peak, 'traffic': None if snn else pmc_traffic(dom), 'avg_launch_ms': cand[dom],
+                    'frac': ach / peak, 'traffic': pmc_traffic(dom, snn), 'avg_launch_ms': cand[dom],
                     # an event-bracketed slot = kernel + the event mechanism (a back-to-back pair alone: 'event_pair_ms');
                     # the kernel-only average of the committed rocprofv3 summary of this command is quoted beside it
                     'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if snn else rocprof_avg_ms(dom),
@@ -562,14 +562,14 @@ def bench_ipnn(args):
         'roofline': roof, 'cpu_baseline': cpu, 'kernel_ms': seg}))
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, snn=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, tools/pmc_traffic.sh; the newest
     profiles/*_pmc_traffic.json, KB).  gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports
     half the bytes of wide coalesced reads, so it is doubled (an upper bound for the mixed access
     widths of these kernels)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_snn.json' if snn else '*_pmc_traffic.json')))
     if not files:
         return None
     tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
