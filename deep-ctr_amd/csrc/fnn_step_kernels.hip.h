@@ -179,7 +179,17 @@ static __global__ __launch_bounds__(256) void k_step2(const SortArgs so, const W
     extern __shared__ __align__(16) unsigned char smem[];
     const int b = blockIdx.x, nw = nwx * splitk;
     if (b < so.nblk) sortA_body<KT>(so, b, smem);                              // so.nblk = 4 * F or 0
-    else if (b < so.nblk + nw) wgrad_body<T>(wa, (b - so.nblk) % nwx, (b - so.nblk) / nwx);
+    else if (b < so.nblk + nw) {
+        // XCD-aware order: hardware block ids that differ by a multiple of 8 share an XCD (and its L2); deal the role's blocks so
+        // that each of the 8 classes owns a contiguous run of (tile, K slice) pairs -- one or two K slices of the operands per XCD
+        // instead of a little of every slice
+        int w = b - so.nblk;
+        if (((b ^ w) & 7) == 0) {                              // the role starts at a multiple of 8
+            const int cls = w & 7, k = w >> 3, qd = nw >> 3, rm = nw & 7;
+            w = (cls < rm ? cls * (qd + 1) : rm * (qd + 1) + (cls - rm) * qd) + k;
+        }
+        wgrad_body<T>(wa, w % nwx, w / nwx);
+    }
     else if (sa.rw == SLOT) scat1_body(sa, b - so.nblk - nw);
     else scatw1_body(sa, b - so.nblk - nw);
 }
