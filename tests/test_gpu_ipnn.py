@@ -275,3 +275,27 @@ def test_ipnn_l7_benchmark_shape_bf16(built):
         cos = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
         assert cos > 0.98, (t, cos)
     eng.close()
+
+
+@pytest.mark.parametrize("env", [{'IPNN_STRIP': '0', 'IPNN_GROUP_WGRAD': '0', 'IPNN_SIDE_STREAM': '0'},
+                                 {'IPNN_STRIP': '0', 'IPNN_GEMM_LDS': '1'}, {'IPNN_MASK_SIDE': '1', 'IPNN_GROUP_XCD': '0', 'IPNN_STRIP_ROT': '0'}])
+def test_ipnn_alternative_paths_match_oracle(built, monkeypatch, env):
+    """The paths the A/B knobs select (one GEMM launch per product -- k_gemm_ft, or the LDS-staged k_gemm_lds at batch
+    4096 --, one launch per weight-gradient product, everything in line on one stream, the side-stream mask
+    transposition, unrotated / launch-order tiles) compute the same step: f32 against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    hidden = [1000, 130]
+    B = 4096 if 'IPNN_GEMM_LDS' in env else 300
+    table, ids, y, params, masks, d = problem(B, hidden, seed=12, scale=0.05)
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='f32', lr=0.01, keep_prob=0.7)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    out = eng.train_step(ids, y, masks, want_logits=True)
+    p0 = [w.copy() for w in params['W']]
+    loss, logits, g = io.sgd_step(params, table, ids, y, 'relu', 0.01, [m.astype(np.float64) for m in masks], 0.7)
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=5e-4, atol=5e-5)
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - p0[t]).max() + 1e-12
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 3e-3 * cw + 3e-7, (t, env)
+    eng.close()
