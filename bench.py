@@ -6,10 +6,15 @@ dims, k=10 (row width K=11), hidden 300/100 tanh, batch 4096 per GPU, bf16 MFMA 
 accumulation and f32 master weights, synthetic Zipf(1.1) ids, inputs resident in HBM.
 A "step" is one pass of the reference's hot loop body (python/FNN_wnzh.py:296-306): gather ->
 train(x, y) -> dense SGD -> sparse-row SGD, for one batch, through the C ABI of libfnn_hip.so.
-N > 1: one process per GPU (torch.distributed.run), batch sharded data-parallel (weak scaling:
-4096 examples per GPU), one RCCL all-reduce of the flat dense-gradient bucket per step.
+N > 1: one process per GPU, batch sharded data-parallel (weak scaling: 4096 examples per GPU), the
+library's native step: the same three launches with ONE RCCL all-reduce (the split-K weight-gradient
+slabs, on the library's own stream) between the second and the third.  `python bench.py --gpus N`
+without a torchrun environment starts the N ranks itself (fresh child processes, before this process
+touches the GPU) and fails if it cannot.
 
-Prints ONE JSON line on rank 0.
+The default N = 1 run also times, briefly, the f32 parity mode of the same step and the other BASELINE
+configs (SNN fine-tune and pre-training, FNN_IP_L7, the standalone gathers) and nests them under
+`precision_f32` / `extra_workloads` of the ONE JSON line rank 0 prints.
 """
 import argparse
 import ctypes as C
@@ -48,6 +53,27 @@ ALGO = {
 STEP_MIN_BYTES = 2180                                    # fused train-step minimum, B/example
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as FRESH child processes (this process has not touched the
+    GPU and does not from here on), pass their output through, exit with their code."""
+    import socket
+    import subprocess
+    import torch
+    rehearse = bool(os.environ.get('FNN_BENCH_REHEARSE'))
+    ndev = torch.cuda.device_count()                      # counting devices does not initialise the GPU
+    if not rehearse and ndev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set FNN_BENCH_REHEARSE=1 for a control-flow rehearsal of "
+                         "the ranks on one GPU over gloo)" % (args.gpus, ndev))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -58,20 +84,107 @@ def main():
     ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam', 'ftrl'],
                     help='--workload ipnn only: sgd (BASELINE configs[2]), or the reference family\'s adam / ftrl (dense table pass per step)')
     ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm'],
-                    help='fnn: BASELINE configs[1] (default).  snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
+                    help='fnn: BASELINE configs[1] (default; at N = 1 the other workloads ride along as extra_workloads).  '
+                         'snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
                          'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
                          'gather: the standalone embedding gathers (A3: FM rows; A8: 200-wide bag rows) against the HBM roofline.  '
                          'rbm: SNN pre-training of configs[4] -- the exact online sparse CD-1 pass and a dense CD-1 layer')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='headline workload only (no precision_f32 / extra_workloads legs)')
+    ap.add_argument('--dp-sparse', default='local', choices=['local', 'exchange'],
+                    help='N > 1: local = every rank applies its own shard\'s row updates (north_star); exchange = the exact mode')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        if args.workload not in ('fnn', 'snn'):
+            raise SystemExit("--gpus %d: only the fnn / snn steps shard (replicas of %s are not launched)" % (args.gpus, args.workload))
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torchrun: bench.py starts the "
+                         "ranks itself)" % (args.gpus, world, args.gpus))
     if args.workload == 'ipnn':
-        return bench_ipnn(args)
-    if args.workload == 'gather':
-        return bench_gather(args)
-    if args.workload == 'rbm':
-        return bench_rbm(args)
+        out = bench_ipnn(args)
+    elif args.workload == 'gather':
+        out = bench_gather(args)
+    elif args.workload == 'rbm':
+        out = bench_rbm(args)
+    else:
+        out = bench_fnn(args, args.precision, args.workload == 'snn')
+        if out is not None and world == 1 and args.workload == 'fnn' and not args.no_extras:
+            import copy
+            short = copy.copy(args)
+            short.steps, short.warmup, short.cpu_seconds = min(args.steps, 100), min(args.warmup, 10), min(args.cpu_seconds, 4.0)
 
+            def leg(fn, *a):
+                try:
+                    r = fn(*a)
+                    return {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline', 'kernel_ms',
+                                                  'train_logloss_last_step', 'sparse_minibatch_4096', 'dense_cd1_200x300',
+                                                  'bag_gather_zipf', 'fm_gather') if k in r}
+                except Exception as e:                    # an extra leg must not cost the headline line
+                    return {'error': '%s: %s' % (type(e).__name__, e)}
+            if args.precision == 'bf16':
+                # the mode that meets the 1e-4 parity bar (tests/test_gpu_parity.py::test_demo_epochs_f32_logloss_auc_within_1e4), timed
+                # on the same workload beside the bf16 headline
+                short.no_cpu_baseline = True
+                out['precision_f32'] = leg(bench_fnn, short, 'f32', False)
+                short.no_cpu_baseline = args.no_cpu_baseline
+            ex = {}
+            ex['snn_finetune'] = leg(bench_fnn, short, args.precision, True)
+            ip = copy.copy(short); ip.steps, ip.warmup = min(args.steps, 50), min(args.warmup, 5)
+            ex['fnn_ip_l7'] = leg(bench_ipnn, ip)
+            ex['gather'] = leg(bench_gather, short)
+            ex['snn_pretrain_rbm'] = leg(bench_rbm, short)
+            out['extra_workloads'] = ex
+            g = ex['gather']
+            if 'error' not in g and out.get('roofline') is not None:
+                # north_star: the gather's achieved fraction of the HBM roofline.  standalone kernels measured in this run;
+                # the gather phase INSIDE the fused strip kernel from the committed per-phase s_memtime stamps (profiles/)
+                out['roofline']['gather'] = {
+                    'standalone_A3_fm_rows': {k: g['fm_gather'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
+                    'standalone_A8_bag_rows_uniform_ids': {k: g['roofline'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
+                    'standalone_A8_bag_rows_zipf_ids': {k: g['bag_gather_zipf'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
+                    'in_step_A3': in_step_gather(args.batch), 'peak': HBM_PEAK_GBS}
+    if out is not None:
+        print(json.dumps(out))
+    teardown_dist()
+
+
+_DIST = None
+
+
+def teardown_dist():
+    global _DIST
+    if _DIST is not None:
+        _DIST.barrier()
+        _DIST.destroy_process_group()
+        _DIST = None
+
+
+def in_step_gather(B):
+    """Gather phase of the fused strip kernel k_step1 (P0: ids, then rows, into the LDS tile), from the newest committed
+    per-phase s_memtime stamps (profiles/*_step1_phases.json; tools/exp/mlp_stamps.hip, a diagnostic build -- the product kernel
+    executes no stamp).  Algorithmic bytes: 64 (ids) + 704 (rows) per example; x is never materialised."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_step1_phases.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    us = d.get('gather_phase_us_median')
+    if not us:
+        return None
+    ach = (64 + 704) * B / (us * 1e-6) / 1e9
+    return {'phase_us_median': us, 'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_per_example': 64 + 704,
+            'source': os.path.basename(files[-1]), 'ids': d.get('ids')}
+
+
+def bench_fnn(args, precision, snn):
+    """The FNN L3 train step (BASELINE configs[1]) or, snn=True, the SNN fine-tune step (configs[4]); every rank calls it,
+    rank 0 gets the result dict (the others None)."""
+    global _DIST
     import torch
     import deep_ctr_amd  # noqa: F401
     from deep_ctr_amd import _capi, synth
@@ -81,22 +194,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dist = None
+    dist = _DIST
+    rehearse = bool(os.environ.get('FNN_BENCH_REHEARSE'))
     force_dp = bool(os.environ.get('FNN_BENCH_FORCE_DP'))      # exercise the DP code path with any world size
-    if world > 1 or force_dp:
+    if (world > 1 or force_dp) and dist is None:
         import torch.distributed as dist
-        if os.environ.get('FNN_BENCH_REHEARSE'):
+        if rehearse:
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if 'MASTER_ADDR' not in os.environ:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
             os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        if os.environ.get('FNN_BENCH_REHEARSE'):              # control-flow rehearsal on ONE GPU: all ranks share cuda:0, gloo collectives
+        if rehearse:              # control-flow rehearsal on ONE GPU: all ranks share cuda:0, gloo collectives
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        _DIST = dist
+    if rehearse:
+        local_rank = 0
     dev = torch.device('cuda', local_rank)
     B = args.batch
     NB = 32                                               # distinct resident batches, cycled
@@ -116,10 +231,9 @@ def main():
     m1_np = o1.draw().astype(np.uint8)
     m2_np = o2.draw().astype(np.uint8)
 
-    snn = args.workload == 'snn'
     H0 = 200
     if snn:       # python/SNN_RBM.py:52-58: H0=200, H1=300, H2=100, lr=.001, dropout=.98, lambda1=0
-        eng = FNNEngine(F, 0, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
+        eng = FNNEngine(F, 0, H1, H2, max_batch=B, precision=precision, lr=0.001, lambda1=0.0,
                         lambda_fm=0.0, reg_all=True, device=local_rank, mode='bag', hidden0=H0)
         ww0 = np.random.default_rng(1234).standard_normal((sum(sizes), H0), dtype=np.float32) * np.float32(0.05)
         eng.set_table(ww0, fo, 0.0)
@@ -129,7 +243,7 @@ def main():
         eng.set_dense({'w1': w1s, 'b1': np.zeros(H1), 'w2': w2s, 'b2': np.zeros(H2), 'w3': np.zeros(H2), 'b3': 0.0})
         del ww0
     else:
-        eng = FNNEngine(F, K, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0,
+        eng = FNNEngine(F, K, H1, H2, max_batch=B, precision=precision, lr=0.001, lambda1=0.0,
                         lambda_fm=0.1, device=local_rank)
         eng.set_table(rows, fo, -3.0)
         eng.set_dense(p0)
@@ -140,27 +254,41 @@ def main():
     torch.cuda.synchronize(dev)
     lib, h = eng.lib, eng.h
     gB = B * world
+
+    # ---- data parallelism: the library's native step (RCCL on its own stream; torch.distributed callbacks in the gloo rehearsal).
+    # Should the native set-up fail on this node, the portable split step with torch.distributed's all-reduce still measures.
+    collective, dp_error, split = None, None, False
+    if dist is not None:
+        from deep_ctr_amd.dp import DataParallelFNN
+        try:
+            dpw = DataParallelFNN(eng, sparse=args.dp_sparse if not snn else 'local')
+            collective = dpw.collective
+        except Exception as e:
+            dp_error = '%s: %s' % (type(e).__name__, e)
+            ok = torch.tensor([0], dtype=torch.int32, device=dev if not rehearse else 'cpu')
+        else:
+            ok = torch.tensor([1], dtype=torch.int32, device=dev if not rehearse else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if int(ok.item()) == 0:
+            if collective is not None:
+                eng.dp_shutdown()
+            split, collective = True, 'torch.distributed all_reduce of the flat bucket (portable split step)'
     bucket = eng.grad_bucket()
 
     def step(i):
-        if not os.environ.get('FNN_BENCH_NOPREFETCH'):
+        if not os.environ.get('FNN_BENCH_NOPREFETCH') and args.dp_sparse == 'local':
             nb = (i + 1) % NB                             # hand the NEXT batch's ids to the library early
             lib.fnn_prefetch_ids(h, ids.data_ptr() + nb * B * F * 4, B)
         b = i % NB
         a = (h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, m1.data_ptr() + b * H1,
              m2.data_ptr() + b * H2, gB)
-        if dist is None:
-            rc = lib.fnn_train_step(*a, None, None, _capi.FNN_MEM_DEVICE, None)
+        if not split:
+            rc = lib.fnn_train_step(*a, None, None, _capi.FNN_MEM_DEVICE, None)       # N > 1: the collective is inside
         else:
             rc = lib.fnn_step_begin(*a, None, None, _capi.FNN_MEM_DEVICE)
             if rc == 0:
-                if os.environ.get('FNN_BENCH_DP_SYNC'):           # experiment: no overlap, the collective in line
-                    dist.all_reduce(bucket)
-                    rc = lib.fnn_step_scatter(h)
-                else:
-                    work = dist.all_reduce(bucket, async_op=True)    # RCCL, ordered after the dense half
-                    rc = lib.fnn_step_scatter(h)                     # sparse half overlaps the collective
-                    work.wait()
+                dist.all_reduce(bucket)                   # ordered on the current stream = the engine's
+                rc = lib.fnn_step_scatter(h)
                 if rc == 0:
                     rc = lib.fnn_step_end(h, None)
         if rc != 0:
@@ -184,7 +312,7 @@ def main():
     eng.sync()
     last_loss = eng.last_loss() / B
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if not rehearse else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -203,7 +331,8 @@ def main():
             step(i)
     sync_all()
     if rank == 0:
-        for name in ('empty', 'step1', 'step2', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
+        for name in ('empty', 'step1', 'step2', 'allreduce', 'allgather', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse',
+                     'sort_global', 'scatter_global', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
                      'scatter', 'finalize'):
             kern_ms[name] = eng.prof_get(name)[0]
         eng.prof_enable(False)
@@ -220,16 +349,29 @@ def main():
             peak, unit = HBM_PEAK_GBS, 'GB/s'
         else:
             ach = per_ex * B / t_s / 1e12
-            peak, unit = MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
+            peak, unit = MFMA_PEAK_TFLOPS[precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
                     'frac': ach / peak, 'traffic': pmc_traffic(dom, snn), 'avg_launch_ms': cand[dom],
                     # an event-bracketed slot = kernel + the event mechanism (a back-to-back pair alone: 'event_pair_ms');
                     # the kernel-only average of the committed rocprofv3 summary of this command is quoted beside it
-                    'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if snn else rocprof_avg_ms(dom),
+                    'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if (snn or precision != 'bf16') else rocprof_avg_ms(dom),
                     'algorithmic_per_example': per_ex,
                     'step': {'achieved': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9,
                              'frac': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              'unit': 'GB/s'}}
+
+    # ---- N > 1: replicas of the exact mode must hold identical tables (a checksum of each rank's table, min == max over ranks)
+    dp_check = None
+    if dist is not None and world > 1 and args.dp_sparse == 'exchange' and not split:
+        try:
+            probe = np.unique(ids_np[:B].ravel())[:4096].astype(np.int64)
+            got = torch.as_tensor(eng.get_rows(probe)).double().sum().reshape(1).to(dev if not rehearse else 'cpu')
+            lo, hi = got.clone(), got.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dp_check = {'rows_probed': int(len(probe)), 'checksum_min': float(lo.item()), 'checksum_max': float(hi.item()),
+                        'replicas_identical': bool(lo.item() == hi.item())}
+        except Exception as e:
+            dp_check = {'error': '%s: %s' % (type(e).__name__, e)}
 
     # ---- CPU baseline: the C port of the oracle on this host, 1 core, bounded sample
     cpu = cpu_vec = None
@@ -260,12 +402,13 @@ def main():
                          'updates in the interpreter as in the reference; host has %d cores)' % (n, B, os.cpu_count())}
         del ww64
 
+    out = None
     if rank == 0:
         out = {
             'metric': 'examples/sec', 'value': value, 'unit': 'examples/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.precision, 'data': 'synthetic',
+            'dtype': precision, 'data': 'synthetic',
             'config': {'workload': ('SNN fine-tune step: 16 fields, 937670 x 200 bag table, hidden 300/100 tanh, batch '
                                     '4096 per GPU, Zipf(1.1) ids' if snn else
                                     'FNN L3 train step: 16 fields, 937670 one-hot dims, k=10, hidden 300/100 '
@@ -276,10 +419,15 @@ def main():
             'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
             'roofline': roofline, 'cpu_baseline': cpu, 'cpu_baseline_vectorised': cpu_vec, 'kernel_ms': kern_ms,
         }
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if dist is not None:
+            out['data_parallel'] = {'collective': collective, 'sparse_rows': args.dp_sparse if not snn else 'local',
+                                    'launches_per_step': 'three + one all-reduce of the split-K weight-gradient slabs' if not split else 'five + all-reduce of the flat bucket',
+                                    'native_setup_error': dp_error, 'exact_mode_check': dp_check,
+                                    'rehearsal_all_ranks_on_one_gpu': rehearse}
+    eng.close()
+    del ids, y, m1, m2
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_rbm(args):
@@ -365,7 +513,9 @@ def bench_rbm(args):
     dt_de = (time.perf_counter() - t0) / args.steps
     lib.rbm_dense_destroy(h)
     per_ex = S * H0 * 4 * 2 + S * 8 + H0 * 4                   # 32 rows read + written, ids/values, uniforms
-    print(json.dumps({
+    del W, vb, unif, unif_b, vidb_d, vvalb_d, X, U
+    torch.cuda.empty_cache()
+    return ({
         'metric': 'examples/sec', 'value': N / dt_sp, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': n_sp, 'warmup': args.warmup,
         'ms_per_step': dt_sp * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'SNN pre-training, sparse RBM layer 937670 x 200, 32 sampled visibles per example, EXACT online CD-1 '
@@ -377,7 +527,7 @@ def bench_rbm(args):
                                   'frac_of_hbm_peak': per_ex_b * N / dt_b / 1e9 / HBM_PEAK_GBS, 'algorithmic_per_example': per_ex_b,
                                   'note': 'rbm_sparse_batch: every example of a mini-batch reads start-of-batch parameters (NOT the reference schedule)'},
         'dense_cd1_200x300': {'examples_per_sec': N / dt_de, 'ms_per_minibatch_of_4096': dt_de * 1e3, 'dtype': args.precision},
-        'cpu_baseline': None}))
+        'cpu_baseline': None})
 
 
 def bench_gather(args):
@@ -434,7 +584,9 @@ def bench_gather(args):
                      'algorithmic_per_example': per_ex, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                      'examples_per_sec': Bk / (ms * 1e-3)}
         eng.close()
-    print(json.dumps({
+        del ids, x
+        torch.cuda.empty_cache()
+    return ({
         'metric': 'examples/sec', 'value': res['fm']['examples_per_sec'], 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': res['fm']['avg_launch_ms'], 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -443,7 +595,7 @@ def bench_gather(args):
         'roofline': dict(res['bag'], kernel='k_bag_ref (A8 gather, uniform ids: every row read misses the caches)', bound='hbm',
                          traffic=None),
         'bag_gather_zipf': res['bag_zipf'], 'fm_gather': res['fm'],
-        'cpu_baseline': None}))
+        'cpu_baseline': None})
 
 
 IP_HIDDEN = [1000, 800, 600, 400, 200, 100, 50]        # python/baseline.py:139 (FNN_IP_L7)
@@ -551,7 +703,10 @@ def bench_ipnn(args):
         cpu = {'value': n_done * B / dtc, 'unit': 'examples/sec', 'cores': threads, 'kind': 'port',
                'sample': '%d steps of batch %d on the same ids / masks (oracle.ipnn_oracle.sgd_step: NumPy float64, BLAS on %d threads; host has %s cores)'
                          % (n_done, B, threads, os.cpu_count())}
-    print(json.dumps({
+    eng.close()
+    del masks, marr, ids, y
+    torch.cuda.empty_cache()
+    return ({
         'metric': 'examples/sec', 'value': B * args.steps / dt, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
@@ -559,7 +714,7 @@ def bench_ipnn(args):
                                'keep_prob 0.5 (mask inputs), batch %d, %s' % (B, args.optimizer.upper()), 'per_gpu_batch': B, 'global_batch': B,
                    'parallelism': 'single'},
         'train_logloss_last_step': loss.value / B, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
-        'roofline': roof, 'cpu_baseline': cpu, 'kernel_ms': seg}))
+        'roofline': roof, 'cpu_baseline': cpu, 'kernel_ms': seg})
 
 
 def pmc_traffic(kernel, snn=False):

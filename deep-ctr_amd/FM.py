@@ -82,12 +82,11 @@ class FM(object):
         B = ids_t.shape[0]
         p = torch.empty(B, dtype=torch.float32, device=self.device) if want_p else None
         loss = C.c_float()
+        if B > 4096:                # one call = ONE optimiser step (python/ipinyou.py:171); splitting it would change the update
+            raise FNNError(_capi.FNN_ERR_ARG, "FM.train_step: batch %d > 4096 (fm_create's largest step)" % B)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        for lo in range(0, B, 4096):                                 # a step per <= 4096 examples
-            hi = min(B, lo + 4096)
-            self._ck(self.lib.fm_train_step(self.h, ids_t[lo:hi].data_ptr(), y_t[lo:hi].data_ptr(), hi - lo, self.lr, self.lam,
-                                            self.reduce_mean, p[lo:hi].data_ptr() if want_p else None,
-                                            C.byref(loss) if want_loss else None))
+        self._ck(self.lib.fm_train_step(self.h, ids_t.data_ptr(), y_t.data_ptr(), B, self.lr, self.lam, self.reduce_mean,
+                                        p.data_ptr() if want_p else None, C.byref(loss) if want_loss else None))
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self._keep = (ids_t, y_t)
         return {'loss': float(loss.value) if want_loss else None, 'p': p}

@@ -17,6 +17,10 @@ FNN_PREC_F32, FNN_PREC_BF16 = 0, 1
 FNN_ACT_TANH, FNN_ACT_SIGMOID, FNN_ACT_LINEAR = 0, 1, 2
 FNN_MEM_HOST, FNN_MEM_DEVICE = 0, 1
 FNN_MODE_FM, FNN_MODE_BAG = 0, 1
+FNN_DP_SPARSE_LOCAL, FNN_DP_SPARSE_EXCHANGE = 0, 1
+# collective callbacks of fnn_dp_init_custom: (ctx, buf, n_floats, stream) / (ctx, send, recv, bytes_per_rank, stream) -> 0 = OK
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class fnn_cfg(C.Structure):
@@ -32,6 +36,7 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> (restype, argtypes): every symbol include/fnn_hip.h declares
 SIGNATURES = {
     "fnn_version": (C.c_char_p, []),
+    "fnn_cfg_size": (C.c_uint64, []),
     "fnn_last_error": (C.c_char_p, [_vp]),
     "fnn_create": (_i, [C.POINTER(fnn_cfg), C.POINTER(_vp)]),
     "fnn_destroy": (_i, [_vp]),
@@ -48,6 +53,10 @@ SIGNATURES = {
     "fnn_gather": (_i, [_vp, _vp, _i, _vp, _i]),
     "fnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.POINTER(_f)]),
     "fnn_prefetch_ids": (_i, [_vp, _vp, _i]),
+    "fnn_dp_unique_id": (_i, [_vp]),
+    "fnn_dp_init": (_i, [_vp, _i, _i, _vp, _i]),
+    "fnn_dp_init_custom": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i]),
+    "fnn_dp_shutdown": (_i, [_vp]),
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "fnn_step_scatter": (_i, [_vp]),
@@ -89,6 +98,7 @@ IPNN_ACTS = {'tanh': 0, 'sigmoid': 1, 'relu': 3}
 # every symbol include/ipnn_hip.h declares
 IPNN_SIGNATURES = {
     "ipnn_last_error": (C.c_char_p, [_vp]),
+    "ipnn_cfg_size": (C.c_uint64, []),
     "ipnn_create": (_i, [C.POINTER(ipnn_cfg), C.POINTER(_vp)]),
     "ipnn_destroy": (_i, [_vp]),
     "ipnn_sync": (_i, [_vp]),
@@ -99,6 +109,7 @@ IPNN_SIGNATURES = {
     "ipnn_set_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_get_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.POINTER(_f)]),
+    "ipnn_set_loss_mean": (_i, [_vp, _i]),
     "ipnn_predict": (_i, [_vp, _vp, _i, _vp]),
     "ipnn_eval": (_i, [_vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ipnn_prof_enable": (_i, [_vp, _i]),
@@ -173,5 +184,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # the structs are declared twice (include/*.h and above): a mismatch would make *_create read past the caller's struct
+    for name, st in (("fnn_cfg_size", fnn_cfg), ("ipnn_cfg_size", ipnn_cfg)):
+        if getattr(lib, name)() != C.sizeof(st):
+            raise ImportError("%s() = %d but ctypes declares %d bytes: _capi.py is out of date with include/*.h"
+                              % (name, getattr(lib, name)(), C.sizeof(st)))
     _lib = lib
     return lib

@@ -3,6 +3,8 @@
 // Atomu2014/deep-ctr) and the Python gather / sparse-update loops around them (:87-96, :299-306).
 // gfx950 only; there is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is opened with dlopen at fnn_dp_init
+#include <dlfcn.h>
 
 #include <algorithm>
 
@@ -79,6 +81,15 @@ struct fnn_handle {
     bool in_step = false, update_pending = false, scatter_pending = false, pend_have_next = false;
     int step_B = 0, pend_Ba = 0;
     int prefetch_hits = 0, prefetch_misses = 0;
+    // data parallelism (fnn_dp_init / fnn_dp_init_custom)
+    bool dp = false, dp_own_comm = false; int dp_rank = 0, dp_world = 1, dp_sparse = FNN_DP_SPARSE_LOCAL;
+    fnn_allreduce_fn dp_allreduce = nullptr; fnn_allgather_fn dp_allgather = nullptr; void* dp_ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int32_t* xg_ids_send = nullptr; int32_t* xg_ids = nullptr; float* xg_gxp = nullptr;    // EXCHANGE: padded shard ids, gathered ids / gx'
+    SortSlot gsl; int gN2 = 0; void* gws = nullptr; size_t gws_bytes = 0;      // grouping of a GLOBAL batch (fnn_step_scatter_global), grown on demand
+    int cpow_cap = 0;                   // entries allocated in cpow_dev
+    bool step_native_dp = false;        // the step in flight runs its own collective (fnn_train_step after fnn_dp_init)
+    int step_bsize = 0;                 // its b_size (the decay table is rebuilt with it when a global batch outgrows the table)
     // profiling
     bool prof = false;
     std::map<std::string, ProfSlot> prof_slots;
@@ -133,7 +144,7 @@ int update_cpow(fnn_handle* h, int b_size, int B) {
     if (c == h->cpow_c && h->cpow_n >= B + 1) return FNN_OK;
     // in-flight kernels may still read the old table
     HIPCHK(h, hipStreamSynchronize(h->st));
-    const int n = h->N2max + 1;
+    const int n = h->cpow_cap;
     h->cpow_host.resize(n);
     for (int i = 0; i < n; ++i) h->cpow_host[i] = std::pow(c, (double)i);
     HIPCHK(h, hipMemcpy(h->cpow_dev, h->cpow_host.data(), n * sizeof(double), hipMemcpyHostToDevice));
@@ -165,6 +176,7 @@ bool mlp_shape_ok(const fnn_handle* h) {
     return cx == 4 && ((c1 == 5 && c2 == 2) || (c1 == 1 && c2 == 1));
 }
 int sort_n2(int B) { int N2 = 256; while (N2 < B) N2 <<= 1; return N2; }
+constexpr int GLOBAL_BATCH_MAX = 32768;        // fnn_step_scatter_global / FNN_DP_SPARSE_EXCHANGE: 8 ranks x 4096 examples
 
 template <typename T> WgradArgs make_wgrad_args(fnn_handle* h, int Ba) {
     WgradArgs wa;
@@ -222,32 +234,41 @@ void launch_sort16(fnn_handle* h, const SortArgs& so) {      // split sort: 256-
 }
 
 // Launches 2 and 3 of a step.  `dense`: weight gradients / slab reduce (+ update); `sparse`: the
-// sparse-row SGD of this batch and the grouping of the next one.  Single-GPU steps run both halves
-// in the same two launches; under data parallelism the dense half goes first (fnn_step_begin) so
-// that the caller's all-reduce of the bucket overlaps the sparse half (fnn_step_scatter).
+// sparse-row SGD of this batch and the grouping of the next one.  Single-GPU and native data-parallel
+// steps run both halves in the same two launches (the data-parallel one with its all-reduce of the slabs
+// between them); the portable split API (fnn_step_begin / _scatter / _end) runs the halves separately.
 template <typename T>
-void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
+void launch_step2(fnn_handle* h, bool dense, bool sparse)
 {
     const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
     const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
     if (h->role_off & 2) dense = false;                     // timing experiments: results are wrong by construction
     if (h->role_off & 4) sparse = false;
     const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
-    {
-        ProfScope ps(h, dense && sparse ? "step2" : (dense ? "step2_dense" : "step2_sparse"), h->st);
-        const WgradArgs wa = make_wgrad_args<T>(h, Ba);
-        const int nwx = dense ? wgrad_blocks(wa) : 0;
-        const int nsc = !sparse ? 0 : (h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256)
-                                              : h->F * SORT_N / 256);
-        SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? 4 * h->F : 0, h->skeys};
-        const dim3 grid(so.nblk + nwx * h->splitk + nsc);
-        if (h->key64)
-            hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 0, h->st, so, wa, nwx,
-                               h->splitk, sa);
-        else
-            hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 0, h->st, so, wa, nwx, h->splitk, sa);
-    }
+    ProfScope ps(h, dense && sparse ? "step2" : (dense ? "step2_dense" : "step2_sparse"), h->st);
+    const WgradArgs wa = make_wgrad_args<T>(h, Ba);
+    const int nwx = dense ? wgrad_blocks(wa) : 0;
+    const int nsc = !sparse ? 0 : (h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256)
+                                          : h->F * SORT_N / 256);
+    SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
+                have_next ? 4 * h->F : 0, h->skeys};
+    const dim3 grid(so.nblk + nwx * h->splitk + nsc);
+    if (grid.x == 0) return;
+    if (h->key64)
+        hipLaunchKernelGGL((k_step2<T, unsigned long long>), grid, dim3(256), 0, h->st, so, wa, nwx,
+                           h->splitk, sa);
+    else
+        hipLaunchKernelGGL((k_step2<T, unsigned>), grid, dim3(256), 0, h->st, so, wa, nwx, h->splitk, sa);
+}
+
+template <typename T>
+void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update)
+{
+    const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
+    const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
+    if (h->role_off & 2) dense = false;
+    if (h->role_off & 4) sparse = false;
+    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
     {
         ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
         const int nred = dense ? (int)((h->nw12 / 4 + 255) / 256) + (int)((h->nw - h->nw12 + h->nbag + 255) / 256) + 1 : 0;
@@ -258,12 +279,14 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
                     have_next ? 16 * h->F : 0, h->skeys};
         const dim3 grid(so.nblk + nred + (sparse ? h->scat2_wgs : 0));    // these workgroups walk the multi-chunk segments
         const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
-        if (h->key64) {
-            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
-            else hipLaunchKernelGGL((k_step3<T, false, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
-        } else {
-            if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
-            else hipLaunchKernelGGL((k_step3<T, false, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+        if (grid.x > 0) {
+            if (h->key64) {
+                if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+                else hipLaunchKernelGGL((k_step3<T, false, unsigned long long>), grid, dim3(256), lds, h->st, so, ta, sa);
+            } else {
+                if (update) hipLaunchKernelGGL((k_step3<T, true, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+                else hipLaunchKernelGGL((k_step3<T, false, unsigned>), grid, dim3(256), lds, h->st, so, ta, sa);
+            }
         }
     }
     if (sparse) {
@@ -274,14 +297,51 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
     }
 }
 
+template <typename T>
+void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
+{
+    launch_step2<T>(h, dense, sparse);
+    launch_step3<T>(h, dense, sparse, update);
+}
+
+// ---- collectives of the native data-parallel step, enqueued on the handle's stream
+int dp_allreduce(fnn_handle* h, float* buf, size_t n, const char* what)
+{
+    ProfScope ps(h, "allreduce", h->st);
+    const int rc = h->dp_allreduce(h->dp_ctx, buf, (int64_t)n, (void*)h->st);
+    if (rc != 0) FAIL(h, FNN_ERR_HIP, std::string("data-parallel all-reduce (") + what + ") failed: " + h->err);
+    return FNN_OK;
+}
+
+int ensure_global_ws(fnn_handle* h, int B_g);
+int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g);
+
+// EXCHANGE: all-gather (ids, gx') of every shard, each padded to ldT rows (empty ids), then the sparse-row SGD of the whole
+// global batch in global example order on this rank
+int dp_exchange_sparse(fnn_handle* h, const int32_t* ids, int B)
+{
+    const int rows = h->ldT, F = h->F;
+    {
+        ProfScope ps(h, "allgather", h->st);
+        const size_t n = (size_t)rows * F;
+        hipLaunchKernelGGL(k_pad_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids, B, F, rows, h->xg_ids_send);
+        int rc = h->dp_allgather(h->dp_ctx, h->xg_ids_send, h->xg_ids, (int64_t)(n * 4), (void*)h->st);
+        if (rc == 0) rc = h->dp_allgather(h->dp_ctx, h->gxp, h->xg_gxp, (int64_t)((size_t)rows * h->K1p * 4), (void*)h->st);
+        if (rc != 0) FAIL(h, FNN_ERR_HIP, "data-parallel all-gather failed: " + h->err);
+    }
+    return scatter_global_impl(h, h->xg_ids, h->xg_gxp, rows * h->dp_world);
+}
+
 // The fast path: three role-split launches on the main stream (fnn_step_kernels.hip.h).
 template <typename T>
 int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* m1,
                   const uint8_t* m2, float* p_out, float* gx_out_dev, bool update)
 {
     const int Ba = rup(B, 256);
+    const bool exchange = update && h->dp && h->dp_sparse == FNN_DP_SPARSE_EXCHANGE;   // the rows are grouped over the GLOBAL batch later
     // grouping of THIS batch: done by the previous step (fnn_prefetch_ids) or right now
-    if (!(h->sorted_ids == ids && h->sorted_B == B)) {
+    if (exchange) { h->next_ids = nullptr; h->next_B = 0; }
+    else if (!(h->sorted_ids == ids && h->sorted_B == B)) {
         h->prefetch_misses++;
         ProfScope ps(h, "sort_now", h->st);
         SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F, h->skeys};
@@ -304,8 +364,22 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
                                 B, h->F, h->K, gx_out_dev);
     }
     h->pend_Ba = Ba; h->pend_have_next = have_next;
-    if (update) launch_steps23<T>(h, true, true, true);          // dense and sparse roles share the launches
-    else { launch_steps23<T>(h, true, false, false); h->scatter_pending = true; }   // DP: sparse half deferred
+    if (update && h->dp) {
+        // native data-parallel step: the same launches with ONE collective between the second and the third -- the split-K
+        // slabs of the weight gradients are all-reduced in place, the third launch then sums GLOBAL slabs
+        const bool local = h->dp_sparse == FNN_DP_SPARSE_LOCAL;
+        launch_step2<T>(h, true, local);
+        int rc = dp_allreduce(h, h->slab, (size_t)h->splitk * h->nslab, "weight-gradient slabs");
+        if (rc != FNN_OK) return rc;
+        launch_step3<T>(h, true, local, true);
+        if (!local) {
+            h->pend_have_next = false;
+            rc = dp_exchange_sparse(h, ids, B);
+            if (rc != FNN_OK) return rc;
+        }
+    }
+    else if (update) launch_steps23<T>(h, true, true, true);     // dense and sparse roles share the launches
+    else { launch_steps23<T>(h, true, false, false); h->scatter_pending = true; }   // split API: sparse half deferred
     HIPCHK(h, hipGetLastError());
     return FNN_OK;
 }
@@ -325,6 +399,8 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     h->sorted_ids = nullptr; h->next_ids = nullptr;            // this path keeps no grouping across steps
     if (h->bag && !(h->fused && mlp_shape_ok(h))) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG needs the strip kernel (hidden sizes 300/100 or <=63/<=63)");
     if (h->bag && train) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG trains through the three-launch path only (B <= 4096)");
+    if (train && h->step_native_dp && h->dp_sparse == FNN_DP_SPARSE_EXCHANGE)
+        FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE runs on the three-launch path only (B <= 4096, hidden sizes the strip kernel is built for)");
 
     if (train) {   // A6 part 1: group the (row, t) pairs
         ProfScope ps(h, "sort", h->st);
@@ -406,6 +482,143 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     return FNN_OK;
 }
 
+// Workspaces for the grouping and the two-level update of a GLOBAL batch of up to N2 (row, t) pairs per field: the per-rank
+// slots are sized for max_batch, a global batch is world times that.  Grown on demand (the first call synchronises).
+int ensure_global_ws(fnn_handle* h, int B_g)
+{
+    int N2 = sort_n2(B_g);
+    if (N2 <= h->gN2 && h->cpow_cap >= B_g + 1) return FNN_OK;
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (N2 > h->gN2) {
+        fnn_handle::SortSlot& sl = h->gsl;
+        for (void* q : {(void*)sl.rec, (void*)sl.part, (void*)sl.owners, (void*)sl.owner_cnt}) if (q) hipFree(q);
+        sl = fnn_handle::SortSlot();
+        int rc;
+        const size_t nchunk = (size_t)N2 / 16;
+        if ((rc = alloc_dev(h, &sl.rec, (size_t)h->F * N2)) != FNN_OK) return rc;
+        if ((rc = alloc_dev(h, &sl.part, (size_t)h->F * nchunk * 2 * SLOT)) != FNN_OK) return rc;
+        if ((rc = alloc_dev(h, &sl.owners, (size_t)h->F * nchunk)) != FNN_OK) return rc;
+        if ((rc = alloc_dev(h, &sl.owner_cnt, (size_t)1)) != FNN_OK) return rc;
+        h->gN2 = N2;
+    }
+    if (h->cpow_cap < N2 + 1) {             // a row can be hit by every example of the global batch
+        hipFree(h->cpow_dev); h->cpow_dev = nullptr;
+        h->cpow_cap = N2 + 1;
+        int rc = alloc_dev(h, &h->cpow_dev, (size_t)h->cpow_cap);
+        if (rc != FNN_OK) return rc;
+        h->cpow_c = -1.0; h->cpow_n = 0;
+        if (h->step_bsize > 0 && (rc = update_cpow(h, h->step_bsize, B_g)) != FNN_OK) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    if (N2 == 16384) HIPCHK(h, hipFuncSetAttribute((const void*)k_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, N2 * 8));
+    else if (N2 == 8192) HIPCHK(h, hipFuncSetAttribute((const void*)k_sort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, N2 * 8));
+    return FNN_OK;
+}
+
+// sparse-row SGD of a global batch in global example order (python/FNN_wnzh.py:299-306): one grouping per field over the
+// global (row, t) keys -- the one-workgroup bitonic sort up to 16,384 keys, rocPRIM's radix sort beyond -- then the
+// two-level segmented update reading the gathered gradients
+int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g)
+{
+    int rc = ensure_global_ws(h, B_g);
+    if (rc != FNN_OK) return rc;
+    if (h->cpow_n < B_g + 1) FAIL(h, FNN_ERR_STATE, "decay table shorter than the global batch");
+    fnn_handle::SortSlot& sl = h->gsl;
+    const int N2 = sort_n2(B_g), F = h->F;
+    {
+        ProfScope ps(h, "sort_global", h->st);
+        if (N2 > 16384) {
+            std::string err;
+            if (group_global(h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt, &h->gws, &h->gws_bytes, err) != 0)
+                FAIL(h, FNN_ERR_HIP, err);
+        } else {
+            const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
+            const dim3 blk(N2 / kpt);
+            if (kpt == 4) hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            else if (kpt == 8) hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            else hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+        }
+    }
+    {
+        ProfScope ps(h, "scatter_global", h->st);
+        ScatArgs sa = make_scat_args(h, sl, N2);
+        sa.gxp = gxp_g;
+        hipLaunchKernelGGL(k_scat1, dim3((unsigned)(((size_t)F * N2 + 255) / 256)), dim3(256), 0, h->st, sa);
+        hipLaunchKernelGGL(k_scat2, dim3(N2 > 4096 ? 256 : 64), dim3(256), 0, h->st, sa);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->next_ids = nullptr; h->next_B = 0;       // no grouping of a later batch rides on this step
+    h->scatter_pending = false;
+    return FNN_OK;
+}
+
+// ---- RCCL, opened at run time: librccl.so.1 is already in the process under PyTorch-ROCm (RTLD_NOLOAD finds that copy: one
+// RCCL per process), otherwise the loader's search path / this library's RUNPATH (/opt/rocm) finds it.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load(std::string& err)
+{
+    if (g_rccl.lib) return FNN_OK;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { err = std::string("cannot open librccl.so.1: ") + dlerror(); return FNN_ERR_HIP; }
+    RcclApi a; a.lib = lib;
+#define RSYM(f) do { a.f = reinterpret_cast<decltype(a.f)>(dlsym(lib, "nccl" #f)); if (!a.f) { err = "librccl: symbol nccl" #f " not found"; return FNN_ERR_HIP; } } while (0)
+    RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(AllReduce); RSYM(AllGather); RSYM(CommDestroy); RSYM(GetErrorString);
+#undef RSYM
+    g_rccl = a;
+    return FNN_OK;
+}
+
+int rccl_allreduce_cb(void* ctx, float* buf, int64_t n, void* stream)
+{
+    fnn_handle* h = static_cast<fnn_handle*>(ctx);
+    const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, h->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r); return -1; }
+    return 0;
+}
+int rccl_allgather_cb(void* ctx, const void* send, void* recv, int64_t bytes, void* stream)
+{
+    fnn_handle* h = static_cast<fnn_handle*>(ctx);
+    const ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)bytes, ncclInt8, h->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return -1; }
+    return 0;
+}
+
+int dp_setup(fnn_handle* h, int rank, int world, int sparse_mode)
+{
+    if (world < 1 || rank < 0 || rank >= world) FAIL(h, FNN_ERR_ARG, "fnn_dp_init: rank / world out of range");
+    if (sparse_mode != FNN_DP_SPARSE_LOCAL && sparse_mode != FNN_DP_SPARSE_EXCHANGE) FAIL(h, FNN_ERR_ARG, "fnn_dp_init: bad sparse_mode");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_init inside a step");
+    if (sparse_mode == FNN_DP_SPARSE_EXCHANGE) {
+        if (h->bag) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE: FNN_MODE_FM only (the bag update has no order to preserve)");
+        if ((int64_t)world * h->ldT > GLOBAL_BATCH_MAX) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE: world * max_batch (rounded up to 256) must be <= 32768");
+        if (!(h->fused && mlp_shape_ok(h)) || h->Bmax > SORT_N) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE runs on the three-launch path only (max_batch <= 4096, hidden sizes the strip kernel is built for)");
+        int rc;
+        const size_t rows = (size_t)h->ldT;
+        if (!h->xg_ids_send && (rc = alloc_dev(h, &h->xg_ids_send, rows * h->F)) != FNN_OK) return rc;
+        if (h->xg_ids) { hipFree(h->xg_ids); h->xg_ids = nullptr; }
+        if (h->xg_gxp) { hipFree(h->xg_gxp); h->xg_gxp = nullptr; }
+        if ((rc = alloc_dev(h, &h->xg_ids, rows * world * h->F)) != FNN_OK) return rc;
+        if ((rc = alloc_dev(h, &h->xg_gxp, rows * world * h->K1p)) != FNN_OK) return rc;
+        if ((rc = ensure_global_ws(h, (int)rows * world)) != FNN_OK) return rc;
+    }
+    h->dp_rank = rank; h->dp_world = world; h->dp_sparse = sparse_mode;
+    h->sorted_ids = nullptr; h->next_ids = nullptr;
+    return FNN_OK;
+}
+
 int check_ready(fnn_handle* h, int B) {
     if (!h) return FNN_ERR_ARG;
     if (B <= 0 || B > h->Bmax) FAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
@@ -419,7 +632,9 @@ int check_ready(fnn_handle* h, int B) {
 
 extern "C" {
 
-const char* fnn_version(void) { return "fnn_hip 0.1 (gfx950)"; }
+const char* fnn_version(void) { return "fnn_hip 0.2 (gfx950)"; }
+
+uint64_t fnn_cfg_size(void) { return (uint64_t)sizeof(fnn_cfg); }
 
 const char* fnn_last_error(const fnn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -508,7 +723,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     }
     h->key64 = true;                                                  // refined when the table is set
     CK(alloc_dev(h, (char**)&h->skeys, (size_t)h->F * SORT_N * 8));
-    CK(alloc_dev(h, &h->cpow_dev, (size_t)h->N2max + 1));
+    h->cpow_cap = h->N2max + 1;
+    CK(alloc_dev(h, &h->cpow_dev, (size_t)h->cpow_cap));
     CK(alloc_dev(h, &h->err_flag, (size_t)1));
     CK(alloc_dev(h, &h->ones_u8, (size_t)(h->H1p + h->H2p), false));
     HK(hipMemsetAsync(h->ones_u8, 1, (size_t)(h->H1p + h->H2p), h->st));
@@ -533,6 +749,9 @@ int fnn_destroy(fnn_handle* h)
     if (!h) return FNN_ERR_ARG;
     hipSetDevice(h->dev);
     if (h->st) hipStreamSynchronize(h->st);
+    if (h->comm && h->dp_own_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (void* q : {(void*)h->xg_ids_send, (void*)h->xg_ids, (void*)h->xg_gxp, (void*)h->gsl.rec, (void*)h->gsl.part, (void*)h->gsl.owners,
+                    (void*)h->gsl.owner_cnt, h->gws}) if (q) hipFree(q);
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
                     h->xp, h->xpT, h->d1, h->d1T, h->d2, h->dl2, h->dl2T, h->dl1, h->dl1T, h->gxp, h->p_buf,
@@ -796,6 +1015,8 @@ static int step_impl(fnn_handle* h, const int32_t* ids, const float* y, int B, c
     }
     const bool fast = h->fused && mlp_shape_ok(h) && B <= SORT_N;
     h->update_pending = !(fast && inline_update);
+    h->step_native_dp = inline_update && h->dp;
+    h->step_bsize = b_size;
     if (fast)
         rc = h->bf16 ? run_step_fast<bf16_t>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update)
                      : run_step_fast<float>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update);
@@ -852,31 +1073,69 @@ int fnn_step_scatter_global(fnn_handle* h, const int32_t* ids_g, const float* gx
     if (!h) return FNN_ERR_ARG;
     if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_scatter_global without fnn_step_begin");
     if (h->bag) FAIL(h, FNN_ERR_ARG, "fnn_step_scatter_global: FNN_MODE_FM only");
-    if (!ids_g || !gxp_g || B_g < 1 || B_g > h->Bmax) FAIL(h, FNN_ERR_ARG, "ids_g / gxp_g null or B_g outside [1, max_batch]");
-    if (h->cpow_n < B_g + 1) FAIL(h, FNN_ERR_STATE, "decay table shorter than the global batch");
+    if (!ids_g || !gxp_g || B_g < 1 || B_g > GLOBAL_BATCH_MAX) FAIL(h, FNN_ERR_ARG, "ids_g / gxp_g null or B_g outside [1, 32768]");
     HIPCHK(h, hipSetDevice(h->dev));
-    // generic kernels: one bitonic sort per field over the global (row, t) keys, then the two-level
-    // segmented update reading the gathered gradients
-    fnn_handle::SortSlot& sl = h->slot[h->cur];
-    const int N2 = sort_n2(B_g), F = h->F;
-    {
-        ProfScope ps(h, "sort_global", h->st);
-        const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
-        const dim3 blk(N2 / kpt);
-        if (kpt == 4) hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
-        else if (kpt == 8) hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
-        else hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
-    }
-    {
-        ProfScope ps(h, "scatter_global", h->st);
-        ScatArgs sa = make_scat_args(h, sl, N2);
-        sa.gxp = gxp_g;
-        hipLaunchKernelGGL(k_scat1, dim3((unsigned)(((size_t)F * N2 + 255) / 256)), dim3(256), 0, h->st, sa);
-        hipLaunchKernelGGL(k_scat2, dim3(64), dim3(256), 0, h->st, sa);
-    }
-    HIPCHK(h, hipGetLastError());
-    h->sorted_ids = nullptr; h->sorted_B = 0; h->next_ids = nullptr; h->next_B = 0;   // slot[cur] now holds the global grouping
-    h->scatter_pending = false;
+    return scatter_global_impl(h, ids_g, gxp_g, B_g);
+}
+
+int fnn_dp_unique_id(void* id128_out)
+{
+    if (!id128_out) { g_create_err = "fnn_dp_unique_id: null pointer"; return FNN_ERR_ARG; }
+    int rc = rccl_load(g_create_err);
+    if (rc != FNN_OK) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return FNN_ERR_HIP; }
+    memcpy(id128_out, &id, sizeof(id));
+    return FNN_OK;
+}
+
+int fnn_dp_shutdown(fnn_handle* h)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_shutdown inside a step");
+    hipSetDevice(h->dev);
+    if (h->st) hipStreamSynchronize(h->st);
+    if (h->comm && h->dp_own_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->dp_own_comm = false;
+    h->dp = false; h->dp_allreduce = nullptr; h->dp_allgather = nullptr; h->dp_ctx = nullptr;
+    h->dp_rank = 0; h->dp_world = 1; h->dp_sparse = FNN_DP_SPARSE_LOCAL;
+    return FNN_OK;
+}
+
+int fnn_dp_init(fnn_handle* h, int rank, int world, const void* id128, int sparse_mode)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!id128) FAIL(h, FNN_ERR_ARG, "fnn_dp_init: null unique id");
+    if (h->dp) { int rc = fnn_dp_shutdown(h); if (rc != FNN_OK) return rc; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = rccl_load(h->err);
+    if (rc != FNN_OK) return rc;
+    rc = dp_setup(h, rank, world, sparse_mode);
+    if (rc != FNN_OK) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    const ncclResult_t r = g_rccl.CommInitRank(&h->comm, world, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; FAIL(h, FNN_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+    h->dp_own_comm = true;
+    h->dp_allreduce = rccl_allreduce_cb; h->dp_allgather = rccl_allgather_cb; h->dp_ctx = h;
+    h->dp = true;
+    return FNN_OK;
+}
+
+int fnn_dp_init_custom(fnn_handle* h, int rank, int world, fnn_allreduce_fn allreduce, fnn_allgather_fn allgather, void* ctx,
+                       int sparse_mode)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (!allreduce || (sparse_mode == FNN_DP_SPARSE_EXCHANGE && !allgather)) FAIL(h, FNN_ERR_ARG, "fnn_dp_init_custom: null callback");
+    if (h->dp) { int rc = fnn_dp_shutdown(h); if (rc != FNN_OK) return rc; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = dp_setup(h, rank, world, sparse_mode);
+    if (rc != FNN_OK) return rc;
+    h->dp_allreduce = allreduce; h->dp_allgather = allgather; h->dp_ctx = ctx;
+    h->dp = true;
     return FNN_OK;
 }
 
@@ -894,6 +1153,10 @@ int fnn_step_end(fnn_handle* h, float* loss_sum_out)
     HIPCHK(h, hipSetDevice(h->dev));
     if (h->scatter_pending) { int rc = fnn_step_scatter(h); if (rc != FNN_OK) return rc; }
     if (h->update_pending) {
+        if (h->step_native_dp) {        // layer-by-layer path under native data parallelism: the flat bucket is what is summed
+            int rc = dp_allreduce(h, h->bucket, h->nw + h->nbag, "dense-gradient bucket");
+            if (rc != FNN_OK) return rc;
+        }
         ProfScope ps(h, "update", h->st);
         if (h->bf16) launch_update<bf16_t>(h, h->bucket, h->cfg.lr); else launch_update<float>(h, h->bucket, h->cfg.lr);
     }

@@ -665,8 +665,10 @@ template <typename T> struct MlpArgs {
 };
 #ifdef FNN_STAMPS
 #define FNN_STAMP(i) do { if (threadIdx.x == 0) a.dbg[(size_t)blk * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define FNN_STAMP_RT(i) do { if (threadIdx.x == 0) a.dbg[(size_t)blk * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
 #else
 #define FNN_STAMP(i) do { } while (0)
+#define FNN_STAMP_RT(i) do { } while (0)
 #endif
 
 // BAG = false: layer one is the concatenation of the F gathered FM rows (FNN, :87-96).
@@ -692,6 +694,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int t0 = blk * 16;
     const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
+    FNN_STAMP_RT(14);
     FNN_STAMP(0);
 
     // small per-column operands first, so that no later load has to wait behind a store
@@ -1056,6 +1059,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         }
     }
     FNN_STAMP(10);
+    FNN_STAMP_RT(15);
 }
 
 template <typename T, int C1, int C2, int CX>
@@ -1554,6 +1558,15 @@ static __global__ void k_copy_cols(const float* __restrict__ src, int ld, int B,
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)B * n) return;
     dst[gid] = src[(gid / n) * ld + gid % n];
+}
+
+// exact data-parallel mode: this rank's ids [B][F] followed by empty slots (-1) up to `rows` rows -- every rank contributes a
+// block of the same size to the all-gather and the gathered order is the global example order
+static __global__ void k_pad_ids(const int32_t* __restrict__ ids, int B, int F, int rows, int32_t* __restrict__ out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)rows * F) return;
+    out[gid] = gid < (size_t)B * F ? ids[gid] : -1;
 }
 
 // helpers for fnn_set_table / fnn_get_table / fnn_get_rows

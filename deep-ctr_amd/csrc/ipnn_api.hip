@@ -284,6 +284,7 @@ template <typename T> struct EpiIpFwd {      // a_t = mask/keep * act(l_t); ones
 template <typename T> struct EpiIpOut {      // logits (column 0), loss, delta = sigmoid(logit) - y
     static constexpr bool TILE = true;
     T* outF; int ld; T* outT; int ldT; const float* y; float* logits; float* loss_t; float* p_out; int B;
+    float gscale;            // 1 for a summed loss, 1 / B for tf.reduce_mean (python/FNN_IP_L7.py:83-86): scales every gradient of the step
     struct Aux { };
     __device__ Aux load(int, int) const { return Aux{}; }
     __device__ void pre(int r0, int col, const f32x4& acc, float v[4]) const { apply(Aux{}, r0, col, acc, v); }
@@ -296,7 +297,7 @@ template <typename T> struct EpiIpOut {      // logits (column 0), loss, delta =
                 const float z = acc[r], p = 1.0f / (1.0f + expf(-z));
                 if (logits) logits[t] = z;
                 if (p_out) p_out[t] = p;
-                if (y) { x = p - y[t]; loss_t[t] = fmaxf(z, 0.f) - z * y[t] + log1pf(expf(-fabsf(z))); }
+                if (y) { x = (p - y[t]) * gscale; loss_t[t] = fmaxf(z, 0.f) - z * y[t] + log1pf(expf(-fabsf(z))); }
             } else if (col == 0 && loss_t) loss_t[t] = 0.f;
             v[r] = x;
         }
@@ -798,6 +799,7 @@ struct ipnn_handle {
     std::vector<int> sk;                         // split-K of each layer's weight-gradient product
     bool adam = false; int64_t adam_t = 0;       // Adam / FTRL: two state tensors beside every variable, dense row-gradient table; step count
     bool ftrl = false;
+    bool loss_mean = false;                      // ipnn_set_loss_mean: the loss is the batch MEAN (gradients scaled by 1 / B)
     std::vector<float*> Wm, Wv; float *tm = nullptr, *tv = nullptr, *tG = nullptr, *bmv = nullptr;
     std::vector<int> d, Dp;                      // d[0..L+1], padded
     float* table16 = nullptr; int64_t n_rows = 0; float* b = nullptr;
@@ -939,7 +941,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             sa.ef[t - 1] = EpiIpFwd<T>{nullptr, h->Dp[t], (T*)h->aT[t], ldT, drop ? h->maskT[t] : nullptr, drop ? inv_keep : 1.0f, h->cfg.act,
                                        h->d[t], B};
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
-                            logits_out, h->loss_t, p_out, B};
+                            logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         sa.dbg = h->stamps; sa.rot = h->strip_rot;
         hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
     } else {
@@ -951,7 +953,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     }
     {
         EpiIpOut<T> e{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
-                      logits_out, h->loss_t, p_out, B};
+                      logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         gemm((const T*)h->a[L], (const T*)h->wf[L], Ba, h->Dp[L + 1], h->Dp[L] / KS, h->Dp[L] / KS, 1, e);
     }
     }
@@ -1070,6 +1072,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
 extern "C" {
 
 const char* ipnn_last_error(const ipnn_handle* h) { return h ? h->err.c_str() : g_ip_err.c_str(); }
+
+uint64_t ipnn_cfg_size(void) { return (uint64_t)sizeof(ipnn_cfg); }
 
 int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
 {
@@ -1319,6 +1323,13 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B, c
         IHK(h, hipMemcpyAsync(loss_sum_out, h->loss_dev, 4, hipMemcpyDeviceToHost, h->st));
         return ipnn_sync(h);
     }
+    return FNN_OK;
+}
+
+int ipnn_set_loss_mean(ipnn_handle* h, int mean)
+{
+    if (!h) return FNN_ERR_ARG;
+    h->loss_mean = mean != 0;
     return FNN_OK;
 }
 

@@ -82,7 +82,76 @@ __global__ __launch_bounds__(MB) void k_metric_auc(const uint32_t* __restrict__ 
     if (threadIdx.x == 0 && s_a[0]) atomicAdd(acc, s_a[0]);
 }
 
+// ---- grouping of a global batch (see metrics.hip.h): key = f << 51 | row << 20 | t, invalid rows = 2^31 - 1
+constexpr int G_TB = 20, G_RB = 31;
+constexpr unsigned long long G_INV = (1ull << G_RB) - 1;
+
+__global__ __launch_bounds__(256) void k_group_keys(const int32_t* __restrict__ ids, int B, int F, int64_t n_rows, int N2,
+                                                    unsigned long long* __restrict__ keys, int* __restrict__ owner_cnt)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid == 0) *owner_cnt = 0;
+    if (gid >= (size_t)F * N2) return;
+    const int f = (int)(gid / N2), t = (int)(gid % N2);
+    unsigned long long row = G_INV;
+    if (t < B) {
+        const int64_t id = ids[(size_t)t * F + f];
+        if (id >= 0 && id < n_rows) row = (unsigned long long)id;
+    }
+    keys[gid] = ((unsigned long long)f << (G_RB + G_TB)) | (row << G_TB) | (unsigned long long)t;
+}
+
+__global__ __launch_bounds__(256) void k_group_rec(const unsigned long long* __restrict__ sorted, int F, int N2, int4* __restrict__ rec)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)F * N2) return;
+    const int f = (int)(gid / N2), pos = (int)(gid % N2);
+    const unsigned long long key = sorted[gid];
+    const unsigned long long row = (key >> G_TB) & G_INV;
+    int4 r = make_int4(-1, 0, 0, 0);
+    if (row != G_INV) {
+        const unsigned long long* q = sorted + (size_t)f * N2;
+        const unsigned long long lo_key = key & ~((1ull << G_TB) - 1), hi_key = lo_key + (1ull << G_TB);
+        int lo = 0, hi = pos;                                   // first index with key >= lo_key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < lo_key) lo = mid + 1; else hi = mid; }
+        const int s = lo;
+        lo = pos + 1; hi = N2;                                  // first index with key >= hi_key
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < hi_key) lo = mid + 1; else hi = mid; }
+        r = make_int4((int)row, (int)(key & ((1ull << G_TB) - 1)), s, lo);
+    }
+    rec[gid] = r;
+}
+
 }  // namespace
+
+int group_global(hipStream_t st, const int32_t* ids, int B, int F, int64_t n_rows, int N2, int4* rec, int* owner_cnt,
+                 void** ws, size_t* ws_bytes, std::string& err)
+{
+    if (B < 1 || N2 < B || N2 > (1 << G_TB) || F < 1 || F > 64 || n_rows >= (int64_t)G_INV) { err = "group_global: shape out of range"; return -1; }
+    const size_t n = (size_t)F * N2;
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0,
+                                            G_TB + G_RB + 6, st);
+    if (e != hipSuccess) { err = std::string("rocprim::radix_sort_keys (size query): ") + hipGetErrorString(e); return -1; }
+    const size_t kb = (n * 8 + 255) / 256 * 256, need = 2 * kb + tmp_bytes + 256;
+    if (*ws_bytes < need) {
+        if (*ws) { hipStreamSynchronize(st); hipFree(*ws); *ws = nullptr; *ws_bytes = 0; }
+        e = hipMalloc(ws, need);
+        if (e != hipSuccess) { err = std::string("hipMalloc (grouping workspace): ") + hipGetErrorString(e); return -1; }
+        *ws_bytes = need;
+    }
+    unsigned long long* keys = static_cast<unsigned long long*>(*ws);
+    unsigned long long* sorted = reinterpret_cast<unsigned long long*>(static_cast<char*>(*ws) + kb);
+    void* tmp = static_cast<char*>(*ws) + 2 * kb;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_group_keys, dim3(nb), dim3(256), 0, st, ids, B, F, n_rows, N2, keys, owner_cnt);
+    e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys, sorted, n, 0, G_TB + G_RB + 6, st);
+    if (e != hipSuccess) { err = std::string("rocprim::radix_sort_keys: ") + hipGetErrorString(e); return -1; }
+    hipLaunchKernelGGL(k_group_rec, dim3(nb), dim3(256), 0, st, sorted, F, N2, rec);
+    e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("group_global launch: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
 
 int device_metrics(hipStream_t st, const float* p, const int32_t* y, int64_t n, double out[4], std::string& err)
 {

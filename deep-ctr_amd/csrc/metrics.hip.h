@@ -11,4 +11,13 @@ namespace fnn {
 // Returns 0, -1 on a HIP error (err set), -2 when only one class is present (auc undefined; the
 // other two are still written).
 int device_metrics(hipStream_t st, const float* p, const int32_t* y, int64_t n, double out[4], std::string& err);
+
+// Grouping of a GLOBAL batch for the exact data-parallel mode (fnn_step_scatter_global beyond the 16,384 keys the one-workgroup
+// bitonic sort holds in LDS): per field f, the (row, t) pairs ids[t][f], t < B, sorted by (row, t) into
+// rec[f * N2 + pos] = {row, t, s, e} -- [s, e) = the positions of the row's run inside the field -- and {-1, 0, 0, 0} for the
+// N2 - (valid entries) slots that follow (ids outside [0, n_rows), t >= B).  N2 >= B, N2 <= 2^20.  rocPRIM's device radix sort
+// orders the F * N2 64-bit keys (a library sort in the parity mode only).  `ws` / `ws_bytes`: workspace owned by the caller,
+// grown here when too small (hipMalloc: the first call synchronises).  Also zeroes *owner_cnt.  Returns 0 or -1 (err set).
+int group_global(hipStream_t st, const int32_t* ids, int B, int F, int64_t n_rows, int N2, int4* rec, int* owner_cnt,
+                 void** ws, size_t* ws_bytes, std::string& err);
 }  // namespace fnn

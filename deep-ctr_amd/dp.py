@@ -12,6 +12,14 @@ step, after which every rank applies ALL row updates in global example order, so
 stay identical to the single-process run (the multi-GPU parity mode).  The decay constant of
 the sparse update uses the GLOBAL batch length (python/FNN_wnzh.py:304).  Dropout rows are per
 batch, not per example, so every rank must be given the same rows.
+
+Two forms of the step (include/fnn_hip.h):
+* native (an FNNEngine on a GPU): the library issues the collective itself on its own stream, between
+  the second and the third launch of the ordinary train step (fnn_dp_init: RCCL, the default under the
+  `nccl` backend; fnn_dp_init_custom with torch.distributed collectives under any other backend, e.g.
+  the gloo rehearsal with every rank on one GPU);
+* portable (any engine with step_begin / step_end, e.g. the CPU test double of tests/test_dp.py): the
+  collective is issued here between the two calls.
 """
 
 
@@ -27,7 +35,7 @@ class DataParallelFNN(object):
     """Wraps an engine exposing step_begin / step_end / stream (FNNEngine on a GPU).  `group` is a
     torch.distributed process group (None = default)."""
 
-    def __init__(self, engine, group=None, sparse='local'):
+    def __init__(self, engine, group=None, sparse='local', native=None):
         import torch.distributed as dist
         assert sparse in ('local', 'exchange')
         self.sparse = sparse
@@ -36,6 +44,33 @@ class DataParallelFNN(object):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.native = hasattr(engine, 'dp_init') if native is None else bool(native)
+        self.collective = None
+        if self.native:
+            self._init_native()
+
+    def _init_native(self):
+        """RCCL inside the library when the process group is RCCL's (one GPU per rank); torch.distributed collectives
+        as the library's callbacks otherwise."""
+        import torch
+        dist, eng = self.dist, self.engine
+        if dist.get_backend(self.group) == 'nccl':
+            box = [eng.dp_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            eng.dp_init(self.rank, self.world, box[0], self.sparse)
+            self.collective = 'rccl (library, on the engine stream)'
+        else:
+            def allreduce(view):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+
+            def allgather(send, recv):
+                parts = list(recv.view(self.world, -1).unbind(0))
+                dist.all_gather(parts, send, group=self.group)
+                for i, p in enumerate(parts):                  # gloo returns copies for non-contiguous outputs
+                    if p.data_ptr() != recv.view(self.world, -1)[i].data_ptr():
+                        recv.view(self.world, -1)[i].copy_(p)
+            eng.dp_init_custom(self.rank, self.world, allreduce, allgather, self.sparse)
+            self.collective = 'torch.distributed/%s (library callbacks)' % dist.get_backend(self.group)
 
     def shard(self, ids, y):
         lo, hi = shard_bounds(len(y), self.world, self.rank)
@@ -44,14 +79,21 @@ class DataParallelFNN(object):
     def train_step_local(self, ids_local, y_local, mask1, mask2, global_batch, want_loss=False):
         """ids_local / y_local: this rank's shard.  Returns the global loss sum if asked."""
         eng = self.engine
+        if self.native:                          # three launches + one collective, all inside fnn_train_step
+            out = eng.train_step(ids_local, y_local, mask1, mask2, b_size=global_batch, want_loss=want_loss)
+            if want_loss:
+                import torch
+                t = torch.tensor([out['loss']], dtype=torch.float64, device=eng.device if self.dist.get_backend(self.group) == 'nccl' else 'cpu')
+                self.dist.all_reduce(t, group=self.group)
+                return float(t.item())
+            return None
         bucket = eng.step_begin(ids_local, y_local, mask1, mask2, b_size=global_batch)
         work = self._all_reduce(bucket)
         if self.sparse == 'exchange':
             self._exchange_sparse(ids_local, len(y_local), global_batch)
         elif hasattr(eng, 'step_scatter'):
             eng.step_scatter()                   # the sparse-row half runs under the collective
-        if work is not None:
-            work.wait()
+        self._wait(work)
         loss = eng.step_end(want_loss=want_loss)
         if want_loss:
             import torch
@@ -59,6 +101,20 @@ class DataParallelFNN(object):
             self.dist.all_reduce(t, group=self.group)
             return float(t.item())
         return None
+
+    def _wait(self, work):
+        """ProcessGroupNCCL's wait() makes the CURRENT stream wait for the collective: it has to be the engine's stream, the one
+        step_end launches the dense update on -- waiting on another stream would let the update read the bucket while the
+        all-reduce is still writing it."""
+        if work is None:
+            return
+        stream = getattr(self.engine, 'stream', None)
+        if stream is not None:
+            import torch
+            with torch.cuda.stream(stream):
+                work.wait()
+        else:
+            work.wait()
 
     def train_step(self, ids, y, mask1, mask2, want_loss=False):
         """ids / y: the GLOBAL batch, identical on every rank; each rank trains its shard."""

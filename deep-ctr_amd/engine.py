@@ -57,6 +57,7 @@ class FNNEngine(object):
         self.h = h
         self.n_rows = 0
         self._bucket = None
+        self.dp_world = 1
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc):
@@ -218,6 +219,62 @@ class FNNEngine(object):
             self._bucket = _tensor_from_ptr(self._torch, ptr.value, n.value, self.device)
         return self._bucket
 
+    # ------------------------------------------------------------------ native data parallelism
+    @staticmethod
+    def dp_unique_id():
+        """Rank 0: the 128-byte ncclUniqueId every rank passes to dp_init (fnn_dp_unique_id)."""
+        lib = _capi.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.fnn_dp_unique_id(buf)
+        if rc != 0:
+            raise FNNError(rc, (lib.fnn_last_error(None) or b'').decode())
+        return buf.raw
+
+    def dp_init(self, rank, world, unique_id, sparse='local'):
+        """fnn_dp_init: from now on train_step() is the data-parallel step (RCCL all-reduce of the weight-gradient slabs
+        between its second and third launch, on the engine's stream).  Collective: every rank calls it."""
+        assert len(unique_id) == 128
+        self._torch.cuda.set_device(self.device)
+        self._ck(self.lib.fnn_dp_init(self.h, int(rank), int(world), C.c_char_p(unique_id),
+                                      _capi.FNN_DP_SPARSE_EXCHANGE if sparse == 'exchange' else _capi.FNN_DP_SPARSE_LOCAL))
+        self.dp_world = int(world)
+
+    def dp_init_custom(self, rank, world, allreduce, allgather=None, sparse='local'):
+        """fnn_dp_init_custom with Python collectives: allreduce(view) sums a float32 tensor view of the library's buffer over the
+        ranks in place; allgather(send_view, recv_view) fills recv (uint8 views; recv = world blocks of len(send)).  Both are
+        called with the engine's stream current and must leave their work ordered on it."""
+        torch = self._torch
+
+        def _ar(ctx, buf, n, stream):
+            try:
+                with torch.cuda.stream(self.stream):
+                    allreduce(_tensor_from_ptr(torch, buf, n, self.device))
+                return 0
+            except Exception:          # an exception cannot cross the C frames: report and fail the step
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def _ag(ctx, send, recv, nbytes, stream):
+            try:
+                with torch.cuda.stream(self.stream):
+                    allgather(_tensor_from_ptr(torch, send, nbytes, self.device, 'u1'),
+                              _tensor_from_ptr(torch, recv, nbytes * world, self.device, 'u1'))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._cb = (_capi.ALLREDUCE_FN(_ar), _capi.ALLGATHER_FN(_ag) if allgather is not None else None)   # kept alive with the engine
+        self._ck(self.lib.fnn_dp_init_custom(self.h, int(rank), int(world), C.cast(self._cb[0], C.c_void_p),
+                                             C.cast(self._cb[1], C.c_void_p) if self._cb[1] is not None else None, None,
+                                             _capi.FNN_DP_SPARSE_EXCHANGE if sparse == 'exchange' else _capi.FNN_DP_SPARSE_LOCAL))
+        self.dp_world = int(world)
+
+    def dp_shutdown(self):
+        self._ck(self.lib.fnn_dp_shutdown(self.h))
+        self.dp_world = 1
+
     def step_scatter(self):
         """Enqueue the sparse-row half of a begun step (overlaps an async all-reduce of the bucket)."""
         self._ck(self.lib.fnn_step_scatter(self.h))
@@ -294,13 +351,13 @@ class FNNEngine(object):
         return ms.value, n.value
 
 
-def _tensor_from_ptr(torch, ptr, n, device):
-    """Zero-copy float32 view of `n` floats of device memory owned by the library."""
+def _tensor_from_ptr(torch, ptr, n, device, kind='f4'):
+    """Zero-copy view of `n` elements (float32, or 'u1' bytes) of device memory owned by the library."""
 
     class _Holder(object):
         pass
 
     hld = _Holder()
-    hld.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False),
+    hld.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': ('<' if kind != 'u1' else '|') + kind, 'data': (int(ptr), False),
                                     'version': 2}
     return torch.as_tensor(hld, device=device)

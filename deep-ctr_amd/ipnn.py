@@ -15,7 +15,7 @@ from .engine import FNNError
 
 class IPNNEngine(object):
     def __init__(self, n_fields, k, hidden, act='relu', max_batch=4096, precision='bf16', lr=1e-4, keep_prob=0.5, device=0,
-                 pairs=True, optimizer='sgd', adam_eps=1e-8, adam_betas=(0.9, 0.999)):
+                 pairs=True, optimizer='sgd', adam_eps=1e-8, adam_betas=(0.9, 0.999), reduce='sum'):
         import torch
         if not torch.cuda.is_available():
             raise FNNError(_capi.FNN_ERR_HIP, "no HIP device visible to PyTorch-ROCm; no CPU fallback")
@@ -33,6 +33,8 @@ class IPNNEngine(object):
         if rc != 0:
             raise FNNError(rc, (self.lib.ipnn_last_error(None) or b'').decode())
         self.h = h
+        self.reduce = reduce                      # 'sum' or 'mean' (python/FNN_IP_L7.py:83-86: anything but 'sum' is the mean)
+        self._ck(self.lib.ipnn_set_loss_mean(self.h, 0 if reduce == 'sum' else 1))
 
     def _ck(self, rc):
         if rc != 0:
@@ -98,7 +100,8 @@ class IPNNEngine(object):
                                           logits.data_ptr() if want_logits else None, C.byref(loss) if want_loss else None))
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self._keep = (ids_t, y_t, mts)
-        return {'loss': float(loss.value) if want_loss else None, 'logits': logits}
+        scale = 1.0 if self.reduce == 'sum' else 1.0 / B     # the library returns the sum of the per-example losses
+        return {'loss': float(loss.value) * scale if want_loss else None, 'logits': logits}
 
     def predict(self, ids):
         torch = self._torch
@@ -142,7 +145,8 @@ class _IPFamily(object):
         self.keep = _reg_argv[0] if mode == 'train' else 1.0
         self.eng = IPNNEngine(X_feas, rank + 1, hidden, act, max_batch=max(batch_size, eval_size, 1), precision=precision,
                               lr=_ptmzr_argv[1], keep_prob=self.keep, pairs=self.PAIRS, optimizer=_ptmzr_argv[0],
-                              adam_eps=_ptmzr_argv[2] if _ptmzr_argv[0] == 'adam' else 1e-8)
+                              adam_eps=_ptmzr_argv[2] if _ptmzr_argv[0] == 'adam' else 1e-8,
+                              reduce='sum' if _ptmzr_argv[-1] == 'sum' else 'mean')     # python/FNN_IP_L7.py:83-86
         lo, hi, seeds, path = _init_argv[1], _init_argv[2], _init_argv[3], _init_argv[-1]
         var_map = pickle.load(open(path, 'rb')) if path else {}
         d = self.eng.d
@@ -166,7 +170,12 @@ class _IPFamily(object):
     def train_step(self, ids, y, masks=None):
         return self.eng.train_step(ids, y, masks)
 
-    def forward(self, ids):
+    def forward(self, ids, v_wts=None):
+        """Predictions for categorical ids [N, X_feas].  The reference's `forward(N, M, v_wts, c_ids, c_wts, ...)`
+        (python/FNN_IP_L7.py:102-106) also takes Criteo's 13 numeric fields, each a value times a row (:103): not built --
+        the path here is the iPinYou shape, one categorical id per field, every weight 1."""
+        if v_wts is not None:
+            raise NotImplementedError("numeric value-weighted fields (python/FNN_IP_L7.py:103) are not built: categorical ids only")
         return self.eng.predict(ids)
 
     def dump(self, model_path):

@@ -86,6 +86,9 @@ typedef struct fnn_cfg {
 typedef struct fnn_handle fnn_handle;
 
 const char* fnn_version(void);
+/* sizeof(fnn_cfg) as the library was compiled.  A binding declares the struct itself (ctypes, cgo, ...):
+ * it must compare its own size with this before the first fnn_create, which reads every field. */
+uint64_t fnn_cfg_size(void);
 /* Message of the last failing call on `h` (or of the last failing fnn_create
  * when h == NULL).  Valid until the next call on that handle. */
 const char* fnn_last_error(const fnn_handle* h);
@@ -137,11 +140,42 @@ int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B,
  * this call and the step that consumes them. */
 int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B);
 
-/* The same pass split for data parallelism: _begin runs everything except the
- * dense SGD and leaves the dense gradients (sum over this rank's examples, the
- * reference loss being a batch SUM, python/FNN_wnzh.py:173) in one flat f32
- * bucket; the caller all-reduces the bucket (RCCL) on fnn_stream(); _end applies
- * theta <- theta - lr * bucket. */
+/* ---- Data parallelism (new: the reference has no distributed code).  One process per GPU; the global batch is cut into
+ * contiguous shards; the loss is a batch SUM (python/FNN_wnzh.py:173), so the dense gradients of the shards add up exactly and
+ * ONE collective per step is the whole exchange.  Tables are replicated.
+ *
+ * Native form: after fnn_dp_init the ordinary fnn_train_step IS the data-parallel step -- the same three launches as on one
+ * GPU with the collective between the second and the third: launch 1 (strips), launch 2 (weight-gradient slabs | sparse-row
+ * SGD level 1 | run sorts), all-reduce of the split-K slabs on the handle's stream, launch 3 (slab reduce + dense SGD | sparse-row
+ * SGD level 2 | rank merge).  b_size must then be the GLOBAL batch length (the decay of the sparse update, :304), and the
+ * dropout rows must be the same on every rank (they are per batch, not per example, :154,166).
+ *   FNN_DP_SPARSE_LOCAL     every rank applies the sparse-row updates of its own shard (replicas drift apart on rows that
+ *                           several ranks touch: the throughput mode)
+ *   FNN_DP_SPARSE_EXCHANGE  (FNN_MODE_FM) the step also all-gathers (ids, gx') of every shard, each padded to max_batch rows,
+ *                           and every rank applies the whole global batch's row updates in global example order: replicas stay
+ *                           identical to a single-process run of the global batch (the parity mode; world * max_batch <= 32768)
+ * The collectives are RCCL's: librccl.so.1 is opened at fnn_dp_init (no link-time dependency), the handle owns its communicator. */
+#define FNN_DP_SPARSE_LOCAL    0
+#define FNN_DP_SPARSE_EXCHANGE 1
+/* Rank 0: a fresh 128-byte ncclUniqueId to hand to every rank (any side channel: torch.distributed, MPI, a file). */
+int fnn_dp_unique_id(void* id128_out);
+/* Every rank, collectively (blocks until all `world` ranks have called it). */
+int fnn_dp_init(fnn_handle* h, int rank, int world, const void* id128, int sparse_mode);
+/* ... or the caller's own collectives in place of RCCL (a gloo rehearsal, MPI, a test double that stands for several ranks).
+ * Each callback must ENQUEUE the operation on `stream` (or complete it before returning) and return 0:
+ *   allreduce(ctx, buf, n_floats, stream)                     in-place f32 sum over the ranks
+ *   allgather(ctx, send, recv, bytes_per_rank, stream)        recv = the ranks' `send` blocks in rank order (EXCHANGE only) */
+typedef int (*fnn_allreduce_fn)(void* ctx, float* buf, int64_t n_floats, void* stream);
+typedef int (*fnn_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int fnn_dp_init_custom(fnn_handle* h, int rank, int world, fnn_allreduce_fn allreduce, fnn_allgather_fn allgather,
+                       void* ctx, int sparse_mode);
+/* Back to single-process steps (destroys the communicator).  fnn_destroy does this too. */
+int fnn_dp_shutdown(fnn_handle* h);
+
+/* Portable form, for a caller that issues the collective itself between two calls: _begin runs everything except the
+ * dense SGD and leaves the dense gradients (sum over this rank's examples) in one flat f32
+ * bucket; the caller all-reduces the bucket on fnn_stream(); _end applies
+ * theta <- theta - lr * bucket.  (Five launches instead of three: the native form above is the fast one.) */
 int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B,
                    const uint8_t* mask1, const uint8_t* mask2, int b_size,
                    float* p_out, float* gx_out, int memkind);

@@ -56,6 +56,8 @@ typedef struct ipnn_cfg {
 typedef struct ipnn_handle ipnn_handle;
 
 const char* ipnn_last_error(const ipnn_handle* h);
+/* sizeof(ipnn_cfg) as the library was compiled (a binding checks its own struct against it). */
+uint64_t ipnn_cfg_size(void);
 int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out);
 int ipnn_destroy(ipnn_handle* h);
 int ipnn_sync(ipnn_handle* h);
@@ -75,6 +77,10 @@ int ipnn_get_layer(ipnn_handle* h, int layer, float* W, float* bias);
  * One SGD step.  logits_out [B] (device, nullable); loss_sum_out (host, nullable: synchronises). */
 int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B,
                     const uint8_t* const* masks, float* logits_out, float* loss_sum_out);
+/* Loss reduction of the following train steps: 0 (default) = tf.reduce_sum, 1 = tf.reduce_mean over the batch
+ * (`_ptmzr_argv[-1]`, python/FNN_IP_L7.py:83-86): every gradient of a step is scaled by 1 / B.  loss_sum_out stays the
+ * SUM of the per-example cross-entropies (divide by B on the host for the mean). */
+int ipnn_set_loss_mean(ipnn_handle* h, int mean);
 /* p_out [B] = sigmoid(logits) without dropout (`test_preds`, FNN_IP_L3.py:81-84). */
 int ipnn_predict(ipnn_handle* h, const int32_t* ids, int B, float* p_out);
 

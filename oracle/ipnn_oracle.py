@@ -65,11 +65,13 @@ def forward(params, table, ids, act_name, masks=None, keep=1.0):
     return l[:, 0], {'e': e, 'ls': ls, 'As': As}
 
 
-def loss_and_grads(params, table, ids, y, act_name, masks=None, keep=1.0):
+def loss_and_grads(params, table, ids, y, act_name, masks=None, keep=1.0, reduce='sum'):
+    """reduce: 'sum' = tf.reduce_sum(log_loss), anything else = tf.reduce_mean (python/FNN_IP_L7.py:83-86)."""
     logits, c = forward(params, table, ids, act_name, masks, keep)
     y = np.asarray(y, dtype=np.float64)
-    loss = float((np.maximum(logits, 0) - logits * y + np.log1p(np.exp(-np.abs(logits)))).sum())
-    d = (1.0 / (1.0 + np.exp(-logits)) - y)[:, None]       # d loss / d l_{L+1}
+    scale = 1.0 if reduce == 'sum' else 1.0 / len(y)
+    loss = float((np.maximum(logits, 0) - logits * y + np.log1p(np.exp(-np.abs(logits)))).sum()) * scale
+    d = (1.0 / (1.0 + np.exp(-logits)) - y)[:, None] * scale       # d loss / d l_{L+1}
     gW, gb = [None] * len(params['W']), [None] * len(params['W'])
     for t in reversed(range(len(params['W']))):
         gW[t] = c['As'][t].T @ d
@@ -87,10 +89,10 @@ def loss_and_grads(params, table, ids, y, act_name, masks=None, keep=1.0):
     return loss, logits, {'W': gW, 'bias': gb, 'b': float(d[:, -1].sum()), 'e': ge}
 
 
-def sgd_step(params, table, ids, y, act_name, lr, masks=None, keep=1.0):
+def sgd_step(params, table, ids, y, act_name, lr, masks=None, keep=1.0, reduce='sum'):
     """One plain-SGD step on every variable; embedding rows of a batch add up their gradients
     (the gradient through tf.concat / tf.slice is a sum).  Mutates params and table."""
-    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep)
+    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep, reduce)
     for t in range(len(params['W'])):
         params['W'][t] = params['W'][t] - lr * g['W'][t]
         params['bias'][t] = params['bias'][t] - lr * g['bias'][t]
@@ -107,12 +109,12 @@ def adam_state(params, table):
             'b': [0.0, 0.0], 'table': (z(table), z(table))}
 
 
-def adam_step(params, table, ids, y, act_name, lr, st, masks=None, keep=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_step(params, table, ids, y, act_name, lr, st, masks=None, keep=1.0, beta1=0.9, beta2=0.999, eps=1e-8, reduce='sum'):
     """One step of TensorFlow's AdamOptimizer (python/tf_util.py:17-20; python/baseline.py:146) on EVERY
     variable: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); m <- beta1 m + (1 - beta1) g; v <- beta2 v +
     (1 - beta2) g^2; theta <- theta - lr_t m / (sqrt(v) + eps).  The table's gradient is dense (zero rows
     for untouched features), so all of its moments decay and all rows move.  Mutates params, table, st."""
-    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep)
+    loss, logits, g = loss_and_grads(params, table, ids, y, act_name, masks, keep, reduce)
     st['t'] += 1
     lr_t = lr * np.sqrt(1 - beta2 ** st['t']) / (1 - beta1 ** st['t'])
 

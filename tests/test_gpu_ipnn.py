@@ -65,7 +65,7 @@ def test_ipnn_step_f32_vs_oracle(built, act, B, hidden, drop):
 def test_ipnn_bf16_and_family_class(built, tmp_path):
     table, ids, y, params, masks, d = problem(256, [400, 400, 200], seed=3, scale=0.05)
     m = FNN_IP_L3(None, None, 256, [table.shape[0], F, K - 1, 400, 400, 200, 'relu'], ['uniform', -0.01, 0.01, [1, 2, 3, 4, 5, 6], None],
-                  ['sgd', 0.01], [0.5], 'train', 0, precision='bf16')
+                  ['sgd', 0.01, 'sum'], [0.5], 'train', 0, precision='bf16')
     m.eng.set_params(table, params['b'], params['W'], params['bias'])
     pr = m.forward(ids).cpu().numpy()
     assert np.abs(pr - io.predict(params, table, ids, 'relu')).max() < 3e-2
@@ -95,7 +95,7 @@ def test_plain_fnn_class_without_pair_products(built, tmp_path):
               'bias': [f32r(rng.uniform(-0.1, 0.1, d[i + 1])) for i in range(3)]}
     masks = [(rng.uniform(size=(B, d[t])) < 0.8).astype(np.uint8) for t in range(3)]
     m = FNN(None, None, B, [table.shape[0], F, K - 1] + hidden + ['tanh'], ['uniform', -0.01, 0.01, [1, 2, 3, 4, 5], None],
-            ['sgd', 0.01], [0.8], 'train', 0, precision='f32')
+            ['sgd', 0.01, 'sum'], [0.8], 'train', 0, precision='f32')
     assert m.eng.d == d
     m.eng.set_params(table, params['b'], params['W'], params['bias'])
     io.USE_PAIRS = False
@@ -117,6 +117,48 @@ def test_plain_fnn_class_without_pair_products(built, tmp_path):
     m.dump(str(tmp_path / 'fnn.pickle'))
     vm = pickle.load(open(tmp_path / 'fnn.pickle', 'rb'))
     assert set(vm) == {'W', 'V', 'b', 'h1_w', 'h1_b', 'h2_w', 'h2_b', 'h3_w', 'h3_b'} and vm['h1_w'].shape == (F * K + 1, 48)
+
+
+@pytest.mark.parametrize("opt", ['sgd', 'adam'])
+def test_mean_reduction_vs_oracle(built, opt):
+    """`_ptmzr_argv[-1]` other than 'sum' is tf.reduce_mean (python/FNN_IP_L7.py:83-86): every gradient of the step is
+    1 / B of the summed one -- under Adam that is NOT a learning-rate change, so it is checked there too."""
+    B, hidden = 96, [40, 24, 12]
+    table, ids, y, params, masks, d = problem(B, hidden, seed=77)
+    lr = 0.5 if opt == 'sgd' else 1e-3
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=256, precision='f32', lr=lr, keep_prob=0.7, optimizer=opt, reduce='mean')
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    st = io.adam_state(params, table)
+    t0, W0 = table.copy(), [w.copy() for w in params['W']]
+    m64 = [m.astype(np.float64) for m in masks]
+    for step in range(2):
+        out = eng.train_step(ids, y, masks, want_logits=True)
+        if opt == 'sgd':
+            loss, logits, _ = io.sgd_step(params, table, ids, y, 'relu', lr, m64, 0.7, reduce='mean')
+        else:
+            loss, logits, _ = io.adam_step(params, table, ids, y, 'relu', lr, st, m64, 0.7, reduce='mean')
+        np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=5e-4, atol=5e-5)
+        assert abs(out['loss'] - loss) <= 5e-5 * max(1.0, abs(loss))          # the mean, as the reference's `loss`
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - W0[t]).max()
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 5e-3 * cw + 1e-7, t
+    touched = np.unique(ids)
+    ct = np.abs(table - t0).max()
+    assert np.abs(eng.get_rows(touched) - table[touched]).max() <= 5e-3 * ct + 1e-7
+    eng.close()
+
+
+def test_family_class_honours_reduce_and_refuses_numeric_fields(built):
+    sizes = synth.field_sizes_tiny(600)
+    net = FNN_IP_L3(sizes, np.cumsum([0] + sizes[:-1]), 32, [sum(sizes), F, K - 1, 24, 16, 8, 'relu'], ['uniform', -0.01, 0.01, [1, 2, 3], None],
+                    ['sgd', 0.1, 'mean'], [0.5], precision='f32')
+    assert net.eng.reduce == 'mean'
+    ids = synth.zipf_ids(8, sizes, 1.1, 3)
+    net.forward(ids)
+    with pytest.raises(NotImplementedError):
+        net.forward(ids, v_wts=np.ones((8, 13), np.float32))
+    net.eng.close()
 
 
 def test_adam_steps_vs_oracle(built):

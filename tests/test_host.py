@@ -55,6 +55,40 @@ def test_header_symbols_are_exported_and_bound(built):
         assert hasattr(lib, name), name
 
 
+def _struct_fields(header, name):
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), header, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    out = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1]
+        out += [n.strip().lstrip('*').split('[')[0] for n in names.split(',')]
+    return out
+
+
+def test_cfg_structs_agree_between_header_ctypes_library_and_integration_doc(built):
+    """The struct is declared in include/*.h, in _capi.py and in INTEGRATION.md's stub: a stale copy makes *_create
+    read past the caller's struct (round-1 finding)."""
+    import ctypes as C
+    lib = _capi.load()
+    hdr = open(os.path.join(ROOT, 'include', 'fnn_hip.h')).read()
+    assert _struct_fields(hdr, 'fnn_cfg') == [n for n, _ in _capi.fnn_cfg._fields_]
+    assert lib.fnn_cfg_size() == C.sizeof(_capi.fnn_cfg)
+    hdr_i = open(os.path.join(ROOT, 'include', 'ipnn_hip.h')).read()
+    assert _struct_fields(hdr_i, 'ipnn_cfg') == [n for n, _ in _capi.ipnn_cfg._fields_]
+    assert lib.ipnn_cfg_size() == C.sizeof(_capi.ipnn_cfg)
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = doc[doc.index('class fnn_cfg(C.Structure):'):doc.index('lib.fnn_cfg_size.restype')]
+    assert re.findall(r'\("([a-z0-9_]+)", C\.', stub) == [n for n, _ in _capi.fnn_cfg._fields_]
+    # the stub's positional constructor call passes exactly one value per field
+    call = doc[doc.index('cfg = fnn_cfg('):doc.index('h = C.c_void_p()')]
+    call = re.sub(r'#.*', '', call)
+    args = call[call.index('(') + 1:call.rindex(')')]
+    assert len([a for a in args.split(',') if a.strip()]) == len(_capi.fnn_cfg._fields_)
+
+
 def test_create_validates_arguments_and_fails_loudly_without_gpu(built):
     import torch
     lib = _capi.load()

@@ -13,6 +13,11 @@ int main() {
     const int64_t D = 937670;
     std::mt19937 rng(1);
     std::vector<int32_t> ids(B * F); for (auto& v : ids) v = rng() % D;
+    const char* ids_kind = "uniform over the table";
+    if (FILE* f = fopen("gpurun_out/zipf_ids.bin", "rb")) {          // the bench's Zipf(1.1) ids of one batch (tools/step1_phases.sh writes them)
+        if (fread(ids.data(), 4, ids.size(), f) == ids.size()) ids_kind = "Zipf(1.1) per field (synth.zipf_ids, the bench's batch 0)";
+        fclose(f);
+    }
     std::vector<float> tab(D * 16); for (auto& v : tab) v = (rng() % 1000) * 1e-4f - 0.05f;
     std::vector<float> y(B, 0.f);
     auto dev = [&](size_t bytes) { void* p; hipMalloc(&p, bytes); hipMemset(p, 0, bytes); return p; };
@@ -52,5 +57,24 @@ int main() {
     long long s0 = hd[0], s1 = hd[0]; for (int b = 0; b < 256; ++b) { s0 = std::min(s0, hd[b * 16]); s1 = std::max(s1, hd[b * 16]); }
     long long e_max = 0; for (int b = 0; b < 256; ++b) e_max = std::max(e_max, hd[b * 16 + 10]);
     printf("%lld ticks; first start -> last end %lld ticks\n", s1 - s0, e_max - s0);
+    // ticks -> microseconds: s_memtime ticks of a workgroup's body over its s_memrealtime (100 MHz) span, median over workgroups
+    std::vector<double> tpu; for (int b = 0; b < 256; ++b) { const long long rt = hd[b * 16 + 15] - hd[b * 16 + 14]; if (rt > 0) tpu.push_back((double)(hd[b * 16 + 10] - hd[b * 16]) / ((double)rt / 100.0)); }
+    std::sort(tpu.begin(), tpu.end());
+    const double ticks_per_us = tpu.empty() ? 2400.0 : tpu[tpu.size() / 2];
+    if (FILE* f = fopen("gpurun_out/step1_phases.json", "w")) {
+        fprintf(f, "{\"kernel\": \"k_step1<bf16, 5, 2, 4> (mlp_body), diagnostic build with s_memtime stamps (tools/exp/mlp_stamps.hip); the product kernel executes no stamp\", ");
+        fprintf(f, "\"batch\": %d, \"workgroups\": 256, \"ids\": \"%s\", \"ticks_per_us\": %.1f, \"launch_us_with_stamps\": %.2f, ", B, ids_kind, ticks_per_us, ms * 1000 / 50);
+        fprintf(f, "\"phases_us_median\": {");
+        for (int i = 0; i < 10; ++i) {
+            std::vector<long long> d; for (int b = 0; b < 256; ++b) d.push_back(hd[b * 16 + i + 1] - hd[b * 16 + i]);
+            std::sort(d.begin(), d.end());
+            fprintf(f, "%s\"%s\": %.3f", i ? ", " : "", names[i], d[128] / ticks_per_us);
+        }
+        std::vector<long long> d0; for (int b = 0; b < 256; ++b) d0.push_back(hd[b * 16 + 1] - hd[b * 16]);
+        std::sort(d0.begin(), d0.end());
+        fprintf(f, "}, \"gather_phase_us_median\": %.3f, \"gather_phase_us_min\": %.3f, \"gather_phase_us_max\": %.3f, \"body_us_median\": %.3f}\n",
+                d0[128] / ticks_per_us, d0[0] / ticks_per_us, d0[255] / ticks_per_us, tot[128] / ticks_per_us);
+        fclose(f);
+    }
     return 0;
 }
