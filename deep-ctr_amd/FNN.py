@@ -13,6 +13,7 @@ import os
 import sys
 import time
 
+import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deep_ctr_amd  # noqa: E402,F401
@@ -87,7 +88,7 @@ def run(argv, out=None):
     eng.set_dense(weights)
     data.engine = eng
 
-    train_ids, train_y = data.load_ids(train_file)             # parsed once, not per epoch
+    train_ids, train_y, train_sh = data.load_ids(train_file, want_shadowed=True)   # parsed once, not per epoch
     test_ids, test_y = data.load_ids(test_file)
 
     train_ids_d, train_y_d = eng.to_device(train_ids, train_y)   # resident in HBM for every epoch's passes
@@ -121,6 +122,12 @@ def run(argv, out=None):
             nlo = (j + 1) * batch_size                         # announce the next batch: its grouping rides on this step's launches
             if j + 1 < n_batch and nlo + 1 <= train_size and len(y) <= 4096:
                 eng.prefetch_ids(train_ids_d[nlo:nlo + batch_size])
+            if len(train_sh):                                  # lines with two features of one field: both rows are updated (:300-306)
+                a, b = np.searchsorted(train_sh[:, 0], [lo, lo + len(y)])
+                if b > a:
+                    sh = train_sh[a:b].copy()
+                    sh[:, 0] -= lo
+                    eng.set_shadowed(sh)
             eng.train_step(ids, y, r1.draw()[0], r2.draw()[0], b_size=len(y), want_loss=False)
         eng.sync()
         print('training: ' + fmt_time(time.time() - start_time))

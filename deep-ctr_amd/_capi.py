@@ -52,6 +52,7 @@ SIGNATURES = {
     "fnn_get_bag_bias": (_i, [_vp, _vp, _i]),
     "fnn_gather": (_i, [_vp, _vp, _i, _vp, _i]),
     "fnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.POINTER(_f)]),
+    "fnn_set_shadowed": (_i, [_vp, _vp, _i, _i]),
     "fnn_prefetch_ids": (_i, [_vp, _vp, _i]),
     "fnn_dp_unique_id": (_i, [_vp]),
     "fnn_dp_init": (_i, [_vp, _i, _i, _vp, _i]),
@@ -156,6 +157,7 @@ CTR_SIGNATURES = {
     "ctr_fm_model_from_arrays": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp)]),
     "ctr_count_lines": (_i, [C.c_char_p, _i, _i64p, _i64p]),
     "ctr_parse_examples": (_i, [C.c_char_p, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _i64p]),
+    "ctr_parse_examples_ex": (_i, [C.c_char_p, _i, _vp, _i, _i, _i64, _vp, _vp, _vp, _i64p, _i64, _vp, _i64p]),
     "ctr_yzx_stat": (_i, [C.c_char_p, _i, _i64p, _i64p, _i64p]),
     "ctr_parse_yzx": (_i, [C.c_char_p, _i, _i64, _i64, _i, _vp, _vp, _vp, _i64p]),
 }

@@ -64,7 +64,11 @@ struct fnn_handle {
     // scatter
     // Grouping results (sorted (row, t) records + level-2 work lists), double-buffered: the slot of
     // the batch being trained and the slot the NEXT batch is grouped into during this step.
-    struct SortSlot { int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr; };
+    // tag_shared / stamp: bag mode, the rows several columns of the slot's batch hold (SortArgs).  One array per slot: the rank
+    // merge of batch n + 1 writes its marks in the same launch in which the update of batch n still reads its own.
+    struct SortSlot { int4* rec = nullptr; double* part = nullptr; int4* owners = nullptr; int* owner_cnt = nullptr;
+                      int* tag_shared = nullptr; int stamp = 0; };
+    int* tag_first = nullptr; int tag_stamp = 0;
     SortSlot slot[2]; int cur = 0;
     const int32_t* sorted_ids = nullptr; int sorted_B = 0;      // what slot[cur] holds (nullptr: nothing)
     const int32_t* next_ids = nullptr; int next_B = 0;          // pending fnn_prefetch_ids request
@@ -81,6 +85,8 @@ struct fnn_handle {
     bool in_step = false, update_pending = false, scatter_pending = false, pend_have_next = false;
     int step_B = 0, pend_Ba = 0;
     int prefetch_hits = 0, prefetch_misses = 0;
+    // features shadowed in the gather that the next step's sparse-row update still visits (fnn_set_shadowed)
+    int32_t* shadow_dev = nullptr; int n_shadow = 0, shadow_cap = 0;
     // data parallelism (fnn_dp_init / fnn_dp_init_custom)
     bool dp = false, dp_own_comm = false; int dp_rank = 0, dp_world = 1, dp_sparse = FNN_DP_SPARSE_LOCAL;
     fnn_allreduce_fn dp_allreduce = nullptr; fnn_allgather_fn dp_allgather = nullptr; void* dp_ctx = nullptr;
@@ -173,7 +179,19 @@ template <typename T> void launch_update(fnn_handle* h, const float* bucket, flo
 // layer-by-layer kernels
 bool mlp_shape_ok(const fnn_handle* h) {
     const int c1 = h->H1p / 64, c2 = h->H2p / 64, cx = h->K1p / 64;
+    if (cx == 5) return h->bag && c1 == 5 && c2 == 2;        // bag rows 256..316 wide: the reference's default hidden0 = 300 (python/SNN_RBM.py:25)
     return cx == 4 && ((c1 == 5 && c2 == 2) || (c1 == 1 && c2 == 1));
+}
+// a fresh stamp for a grouping about to be written into `sl` (bag mode; see SortArgs).  2^25 groupings, then the tags start over.
+int next_stamp(fnn_handle* h, fnn_handle::SortSlot& sl) {
+    if (!h->bag) return 0;
+    if (h->tag_stamp >= (1 << 25) - 1) {
+        hipMemsetAsync(h->tag_first, 0, (size_t)h->n_rows * sizeof(int), h->st);
+        for (auto& q : h->slot) hipMemsetAsync(q.tag_shared, 0, (size_t)h->n_rows * sizeof(int), h->st);
+        h->tag_stamp = 0;
+    }
+    sl.stamp = ++h->tag_stamp;
+    return sl.stamp;
 }
 int sort_n2(int B) { int N2 = 256; while (N2 < B) N2 <<= 1; return N2; }
 constexpr int GLOBAL_BATCH_MAX = 32768;        // fnn_step_scatter_global / FNN_DP_SPARSE_EXCHANGE: 8 ranks x 4096 examples
@@ -192,7 +210,7 @@ int wgrad_blocks(const WgradArgs& wa) {
 }
 ScatArgs make_scat_args(fnn_handle* h, const fnn_handle::SortSlot& sl, int N2) {
     return ScatArgs{sl.rec, N2, h->F, h->K, h->gxp, h->K1p, h->cpow_dev, (double)h->cfg.lr, h->table16,
-                    sl.part, sl.owner_cnt, sl.owners, h->rw};
+                    sl.part, sl.owner_cnt, sl.owners, h->rw, sl.tag_shared, sl.stamp};
 }
 template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids, const float* y, int B,
                                                 const uint8_t* m1, const uint8_t* m2, bool train, float* p_out) {
@@ -212,8 +230,13 @@ template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int
 }
 template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
     const bool big = h->H1p / 64 == 5;
-    const size_t lds = big ? mlp_lds_bytes<T, 5, 2, 4>(h->bag, h->F) : mlp_lds_bytes<T, 1, 1, 4>(h->bag, h->F);
     const dim3 g(nmlp), b(256);
+    if (h->K1p / 64 == 5) {                                      // bag mode only (mlp_shape_ok)
+        const size_t lds5 = mlp_lds_bytes<T, 5, 2, 5>(true, h->F);
+        hipLaunchKernelGGL((k_step1<T, 5, 2, 5, true>), g, b, lds5, h->st, a);
+        return;
+    }
+    const size_t lds = big ? mlp_lds_bytes<T, 5, 2, 4>(h->bag, h->F) : mlp_lds_bytes<T, 1, 1, 4>(h->bag, h->F);
     if (h->bag) {
         if (big) hipLaunchKernelGGL((k_step1<T, 5, 2, 4, true>), g, b, lds, h->st, a);
         else hipLaunchKernelGGL((k_step1<T, 1, 1, 4, true>), g, b, lds, h->st, a);
@@ -251,7 +274,7 @@ void launch_step2(fnn_handle* h, bool dense, bool sparse)
     const int nsc = !sparse ? 0 : (h->bag ? (int)(((size_t)h->F * (SORT_N / WCH) * (h->rw / 4) + 255) / 256)
                                           : h->F * SORT_N / 256);
     SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                have_next ? 4 * h->F : 0, h->skeys};
+                have_next ? 4 * h->F : 0, h->skeys, nullptr, nullptr, 0};
     const dim3 grid(so.nblk + nwx * h->splitk + nsc);
     if (grid.x == 0) return;
     if (h->key64)
@@ -275,8 +298,9 @@ void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update)
         TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
                     h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
                     h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
+        const int stamp = have_next ? next_stamp(h, h->slot[nxt]) : 0;      // the rank merge of the NEXT batch marks its shared rows
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
-                    have_next ? 16 * h->F : 0, h->skeys};
+                    have_next ? 16 * h->F : 0, h->skeys, h->tag_first, h->slot[nxt].tag_shared, stamp};
         const dim3 grid(so.nblk + nred + (sparse ? h->scat2_wgs : 0));    // these workgroups walk the multi-chunk segments
         const size_t lds = h->key64 ? sort_lds_bytes<unsigned long long>() : sort_lds_bytes<unsigned>();
         if (grid.x > 0) {
@@ -344,7 +368,8 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
     else if (!(h->sorted_ids == ids && h->sorted_B == B)) {
         h->prefetch_misses++;
         ProfScope ps(h, "sort_now", h->st);
-        SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F, h->skeys};
+        SortArgs so{ids, B, h->F, h->n_rows, h->slot[h->cur].rec, h->slot[h->cur].owner_cnt, h->F, h->skeys,
+                    h->tag_first, h->slot[h->cur].tag_shared, next_stamp(h, h->slot[h->cur])};
         launch_sort16(h, so);
     } else h->prefetch_hits++;
     const bool have_next = h->next_ids != nullptr && !(h->next_ids == ids && h->next_B == B);
@@ -393,9 +418,16 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
     const int F = h->F, K = h->K, K1p = h->K1p, H1p = h->H1p, H2p = h->H2p, ldT = h->ldT;
     T *xp = (T*)h->xp, *xpT = (T*)h->xpT, *d1 = (T*)h->d1, *d1T = (T*)h->d1T, *d2 = (T*)h->d2,
       *dl2 = (T*)h->dl2, *dl2T = (T*)h->dl2T, *dl1 = (T*)h->dl1, *dl1T = (T*)h->dl1T;
-    const int N2 = sort_n2(B);
+    // shadowed features join their field's keys behind the B regular ones: room for all of them in any one field
+    const int nsh = train ? h->n_shadow : 0;
+    const int N2 = sort_n2(B + nsh);
     T *d2T = (T*)h->d2T, *dl3T = (T*)h->dl3T;
-    fnn_handle::SortSlot& sl = h->slot[h->cur];
+    if (nsh > 0) {
+        if (B + nsh > 16384) FAIL(h, FNN_ERR_ARG, "batch plus shadowed features exceed 16384 keys per field");
+        int rc = ensure_global_ws(h, B + nsh);                 // the per-batch slots hold max_batch keys per field
+        if (rc != FNN_OK) return rc;
+    }
+    fnn_handle::SortSlot& sl = nsh > 0 ? h->gsl : h->slot[h->cur];
     h->sorted_ids = nullptr; h->next_ids = nullptr;            // this path keeps no grouping across steps
     if (h->bag && !(h->fused && mlp_shape_ok(h))) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG needs the strip kernel (hidden sizes 300/100 or <=63/<=63)");
     if (h->bag && train) FAIL(h, FNN_ERR_ARG, "FNN_MODE_BAG trains through the three-launch path only (B <= 4096)");
@@ -407,11 +439,11 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
         const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
         const dim3 blk(N2 / kpt);
         if (kpt == 4)
-            hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt, h->shadow_dev, h->n_shadow, h->err_flag);
         else if (kpt == 8)
-            hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt, h->shadow_dev, h->n_shadow, h->err_flag);
         else
-            hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids, B, F, h->n_rows, N2, sl.rec, sl.owner_cnt, h->shadow_dev, h->n_shadow, h->err_flag);
     }
     if (h->fused && mlp_shape_ok(h)) {
         ProfScope ps(h, "mlp", h->st);
@@ -534,9 +566,9 @@ int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g,
         } else {
             const int kpt = N2 <= 4096 ? 4 : (N2 == 8192 ? 8 : 16);
             const dim3 blk(N2 / kpt);
-            if (kpt == 4) hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
-            else if (kpt == 8) hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
-            else hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt);
+            if (kpt == 4) hipLaunchKernelGGL(k_sort<4>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt, nullptr, 0, h->err_flag);
+            else if (kpt == 8) hipLaunchKernelGGL(k_sort<8>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt, nullptr, 0, h->err_flag);
+            else hipLaunchKernelGGL(k_sort<16>, dim3(F), blk, (size_t)N2 * 8, h->st, ids_g, B_g, F, h->n_rows, N2, sl.rec, sl.owner_cnt, nullptr, 0, h->err_flag);
         }
     }
     {
@@ -644,8 +676,8 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     *out = nullptr;
     if (cfg->n_fields < 2 || cfg->n_fields > 64) { g_create_err = "n_fields must be in [2, 64]"; return FNN_ERR_ARG; }
     if (cfg->mode != FNN_MODE_FM && cfg->mode != FNN_MODE_BAG) { g_create_err = "bad mode"; return FNN_ERR_ARG; }
-    if (cfg->mode == FNN_MODE_BAG && (cfg->h0 < 4 || cfg->h0 > 252 || cfg->h0 % 4 != 0)) {
-        g_create_err = "FNN_MODE_BAG: h0 must be a multiple of 4 in [4, 252]"; return FNN_ERR_ARG; }
+    if (cfg->mode == FNN_MODE_BAG && (cfg->h0 < 192 || cfg->h0 > 316 || cfg->h0 % 4 != 0)) {
+        g_create_err = "FNN_MODE_BAG: h0 must be a multiple of 4 in [192, 316] (the strip kernel is built for bag rows of 256 or 320 padded floats; the reference uses 200 and 300, python/SNN_RBM.py:25,53)"; return FNN_ERR_ARG; }
     if (cfg->mode == FNN_MODE_FM && (cfg->k < 1 || cfg->k > 15)) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
     if (cfg->hidden1 < 1 || cfg->hidden1 > 4095 || cfg->hidden2 < 1 || cfg->hidden2 > 255) { g_create_err = "hidden1 must be in [1, 4095], hidden2 in [1, 255]"; return FNN_ERR_ARG; }
     if (cfg->max_batch < 1 || cfg->max_batch > 16384) { g_create_err = "max_batch must be in [1, 16384] (per-field LDS sort)"; return FNN_ERR_ARG; }
@@ -708,7 +740,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
         CK(alloc_dev(h, &sl.owner_cnt, (size_t)1));
     }
     if (h->bag) {
-        if (!mlp_shape_ok(h)) { h->err = "FNN_MODE_BAG needs hidden sizes the strip kernel is built for (300/100 or <=63/<=63)"; return fail(FNN_ERR_ARG); }
+        if (!mlp_shape_ok(h)) { h->err = "FNN_MODE_BAG needs hidden sizes the strip kernel is built for (hidden1 257..319 with hidden2 65..127, e.g. 300/100; h0 <= 252 also <=63/<=63)"; return fail(FNN_ERR_ARG); }
         CK(alloc_dev(h, &h->bb0, (size_t)h->K1p));
         CK(alloc_dev(h, (char**)&h->dlxT, Ba * h->K1p * ts));
         CK(alloc_dev(h, (char**)&h->onesT, Ba * 64 * ts));
@@ -750,7 +782,7 @@ int fnn_destroy(fnn_handle* h)
     hipSetDevice(h->dev);
     if (h->st) hipStreamSynchronize(h->st);
     if (h->comm && h->dp_own_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    for (void* q : {(void*)h->xg_ids_send, (void*)h->xg_ids, (void*)h->xg_gxp, (void*)h->gsl.rec, (void*)h->gsl.part, (void*)h->gsl.owners,
+    for (void* q : {(void*)h->tag_first, (void*)h->slot[0].tag_shared, (void*)h->slot[1].tag_shared, (void*)h->shadow_dev, (void*)h->xg_ids_send, (void*)h->xg_ids, (void*)h->xg_gxp, (void*)h->gsl.rec, (void*)h->gsl.part, (void*)h->gsl.owners,
                     (void*)h->gsl.owner_cnt, h->gws}) if (q) hipFree(q);
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     void* ptrs[] = {h->table16, h->field_of_row, h->master, h->bucket, h->slab, h->w1, h->w1t, h->w2, h->w2t,
@@ -809,6 +841,14 @@ int fnn_set_table(fnn_handle* h, const float* rows, int64_t n_rows, const int32_
         HIPCHK(h, hipMemsetAsync(h->field_of_row, 0, (size_t)n_rows * sizeof(int32_t), h->st));
     HIPCHK(h, hipStreamSynchronize(h->st));
     if (tmp) hipFree(tmp);
+    if (h->bag) {
+        for (int** q : {&h->tag_first, &h->slot[0].tag_shared, &h->slot[1].tag_shared}) {
+            if (*q) { hipFree(*q); *q = nullptr; }
+            HIPCHK(h, hipMalloc((void**)q, (size_t)n_rows * sizeof(int)));
+            HIPCHK(h, hipMemset(*q, 0, (size_t)n_rows * sizeof(int)));
+        }
+        h->tag_stamp = 0;
+    }
     h->n_rows = n_rows; h->w0 = w0;
     h->key64 = (unsigned long long)n_rows * SORT_N > 0xFFFFFFFFull;     // else 32-bit (row << 12 | t) keys
     h->sorted_ids = nullptr; h->next_ids = nullptr;
@@ -1013,7 +1053,11 @@ static int step_impl(fnn_handle* h, const int32_t* ids, const float* y, int B, c
         if (gx_out) gx_d = h->st_x;
         h->sorted_ids = nullptr; h->next_ids = nullptr;     // staging buffers are reused: no carried grouping
     }
-    const bool fast = h->fused && mlp_shape_ok(h) && B <= SORT_N;
+    if (h->n_shadow > 0 && h->bag) FAIL(h, FNN_ERR_ARG, "fnn_set_shadowed: FNN_MODE_FM only");
+    if (h->n_shadow > 0 && h->dp && inline_update && h->dp_sparse == FNN_DP_SPARSE_EXCHANGE)
+        FAIL(h, FNN_ERR_ARG, "shadowed features are not carried through FNN_DP_SPARSE_EXCHANGE");
+    // shadowed features: the layer-by-layer path, whose per-field sort has room for the extra keys
+    const bool fast = h->fused && mlp_shape_ok(h) && B <= SORT_N && h->n_shadow == 0;
     h->update_pending = !(fast && inline_update);
     h->step_native_dp = inline_update && h->dp;
     h->step_bsize = b_size;
@@ -1023,6 +1067,7 @@ static int step_impl(fnn_handle* h, const int32_t* ids, const float* y, int B, c
     else
         rc = h->bf16 ? run_step<bf16_t>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d)
                      : run_step<float>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d);
+    h->n_shadow = 0;                                            // consumed (also by a failing step)
     if (rc != FNN_OK) return rc;
     if (memkind == FNN_MEM_HOST) {
         if (p_out) HIPCHK(h, hipMemcpyAsync(p_out, p_d, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
@@ -1037,6 +1082,28 @@ int fnn_step_begin(fnn_handle* h, const int32_t* ids, const float* y, int B, con
                    const uint8_t* mask2, int b_size, float* p_out, float* gx_out, int memkind)
 {
     return step_impl(h, ids, y, B, mask1, mask2, b_size, p_out, gx_out, memkind, false);
+}
+
+int fnn_set_shadowed(fnn_handle* h, const int32_t* tfr, int n, int memkind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (n < 0 || (n > 0 && !tfr)) FAIL(h, FNN_ERR_ARG, "fnn_set_shadowed: null list or n < 0");
+    if (h->bag) FAIL(h, FNN_ERR_ARG, "fnn_set_shadowed: FNN_MODE_FM only");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_set_shadowed inside a step");
+    HIPCHK(h, hipSetDevice(h->dev));
+    if (n > h->shadow_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->st));
+        if (h->shadow_dev) { hipFree(h->shadow_dev); h->shadow_dev = nullptr; h->shadow_cap = 0; }
+        const int cap = std::max(1024, n);
+        HIPCHK(h, hipMalloc((void**)&h->shadow_dev, (size_t)cap * 3 * sizeof(int32_t)));
+        h->shadow_cap = cap;
+    }
+    if (n > 0)
+        HIPCHK(h, hipMemcpyAsync(h->shadow_dev, tfr, (size_t)n * 3 * sizeof(int32_t),
+                                 memkind == FNN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
+    if (n > 0 && memkind == FNN_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->st));       // the caller's buffer may go away
+    h->n_shadow = n;
+    return FNN_OK;
 }
 
 int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B)

@@ -1227,14 +1227,34 @@ static __global__ void k_update(float* __restrict__ master, const float* __restr
 //             order and writes the row.  No float atomics anywhere: the result is bitwise
 //             reproducible.
 // ------------------------------------------------------------------------------------------
+// `extra` [n_extra][3] = (example t, field, row): features of a line that a LATER feature of the same field shadowed in the
+// gather (python/FNN_wnzh.py:91-96 keeps the last) but that the reference's update loop still visits (:300-306 walks every
+// feature of the line).  They join their field's keys as (row, t) pairs behind the B regular ones, so that a row's decay
+// powers and gradient terms count every visit in example order; N2 >= B + (extras of any one field).
 template <int KPT>
 static __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict__ ids, int B, int F,
                                                int64_t n_rows, int N2, int4* __restrict__ rec,
-                                               int* __restrict__ owner_cnt)
+                                               int* __restrict__ owner_cnt, const int32_t* __restrict__ extra, int n_extra,
+                                               int* __restrict__ err)
 {
     extern __shared__ unsigned long long s_key[];
+    __shared__ int s_cnt;
     const int f = blockIdx.x, tid = threadIdx.x;       // blockDim.x == N2 / KPT
     if (f == 0 && tid == 0) *owner_cnt = 0;
+    int cnt = 0;
+    if (n_extra > 0) {                                 // wave-uniform: the common case pays one compare
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int j = tid; j < n_extra; j += blockDim.x) {
+            const int t = extra[3 * j], ff = extra[3 * j + 1]; const int64_t r = extra[3 * j + 2];
+            if (ff < 0 || ff >= F || t < 0 || t >= B || r < 0 || r >= n_rows) { if (f == 0) atomicOr(err, 1); continue; }
+            if (ff != f) continue;
+            const int p = atomicAdd(&s_cnt, 1);
+            if (B + p < N2) s_key[B + p] = ((unsigned long long)r << 32) | (unsigned)t;
+        }
+        __syncthreads();
+        cnt = min(s_cnt, N2 - B);
+    }
     unsigned long long key[KPT];
 #pragma unroll
     for (int a = 0; a < KPT; ++a) {
@@ -1243,9 +1263,10 @@ static __global__ __launch_bounds__(1024) void k_sort(const int32_t* __restrict_
         if (i < B) {
             const int64_t id = ids[(size_t)i * F + f];
             if (id >= 0 && id < n_rows) kk = ((unsigned long long)id << 32) | (unsigned)i;
-        }
+        } else if (i < B + cnt) kk = s_key[i];
         key[a] = kk;
     }
+    if (n_extra > 0) __syncthreads();                  // s_key is reused by the exchange stages
     for (int k = 2; k <= N2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j < KPT) {                              // both elements live in this thread
@@ -1316,7 +1337,13 @@ struct ScatArgs {
     const int4* rec; int N2, F, K; const float* gxp; int K1p; const double* cpow; double lr;
     float* table16; double* part; int* owner_cnt; int4* owners;
     int rw;          // 16: FM rows (decayed update); otherwise the bag-table row width (plain sum)
+    const int* tag_shared; int stamp;     // bag mode: tag_shared[row] == stamp <=> the row sits in several columns of this batch (SortArgs)
 };
+// bag rows held by several columns of a batch: every column adds its sum with float atomics (a row touched by one column
+// only -- the rule on iPinYou lines -- keeps the plain read-modify-write, one rounding)
+__device__ __forceinline__ void atomic_add4(float* p, float a, float b, float c, float d) {
+    atomicAdd(p, a); atomicAdd(p + 1, b); atomicAdd(p + 2, c); atomicAdd(p + 3, d);
+}
 __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
 {
     const int4* __restrict__ rec = sa.rec; const int N2 = sa.N2, F = sa.F, K = sa.K, K1p = sa.K1p;
@@ -1461,9 +1488,13 @@ __device__ __forceinline__ void scatw1_body(const ScatArgs& sa, const int blk)
             const int pos = base + sb + j, s = r[j].z, e = r[j].w;
             if (pos + 1 != e && pos + 1 != base + WCH) continue;       // the run goes on inside this chunk
             if (s >= base && e <= base + WCH) {                      // the whole segment lies in this chunk
-                *reinterpret_cast<float4*>(sa.table16 + (size_t)r[j].x * rw + 4 * q) =
-                    make_float4((float)(wold[j].x - sa.lr * a0), (float)(wold[j].y - sa.lr * a1),
-                                (float)(wold[j].z - sa.lr * a2), (float)(wold[j].w - sa.lr * a3));
+                float* dst = sa.table16 + (size_t)r[j].x * rw + 4 * q;
+                if (sa.tag_shared[r[j].x] == sa.stamp)
+                    atomic_add4(dst, (float)(-sa.lr * a0), (float)(-sa.lr * a1), (float)(-sa.lr * a2), (float)(-sa.lr * a3));
+                else
+                    *reinterpret_cast<float4*>(dst) =
+                        make_float4((float)(wold[j].x - sa.lr * a0), (float)(wold[j].y - sa.lr * a1),
+                                    (float)(wold[j].z - sa.lr * a2), (float)(wold[j].w - sa.lr * a3));
             } else {
                 const int which = (s < base) ? 0 : 1;
                 double* pp = sa.part + (((size_t)f * NQ + qc) * 2 + which) * rw + 4 * q;
@@ -1511,8 +1542,11 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
                 const double* d = s_w + ((size_t)gI * nq + q) * 4;
                 t0 += d[0]; t1 += d[1]; t2 += d[2]; t3 += d[3];
             }
-            *p = make_float4((float)(w.x - sa.lr * t0), (float)(w.y - sa.lr * t1), (float)(w.z - sa.lr * t2),
-                             (float)(w.w - sa.lr * t3));
+            if (sa.tag_shared[ow.w] == sa.stamp)
+                atomic_add4(reinterpret_cast<float*>(p), (float)(-sa.lr * t0), (float)(-sa.lr * t1), (float)(-sa.lr * t2), (float)(-sa.lr * t3));
+            else
+                *p = make_float4((float)(w.x - sa.lr * t0), (float)(w.y - sa.lr * t1), (float)(w.z - sa.lr * t2),
+                                 (float)(w.w - sa.lr * t3));
         }
         __syncthreads();
     }

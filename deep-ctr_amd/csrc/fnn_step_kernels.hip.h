@@ -26,7 +26,16 @@ template <typename KT> struct KeyTraits;
 template <> struct KeyTraits<unsigned> { static constexpr int SH = 12; };
 template <> struct KeyTraits<unsigned long long> { static constexpr int SH = 32; };
 
-struct SortArgs { const int32_t* ids; int B, F; int64_t n_rows; int4* rec; int* owner_cnt; int nblk; void* skeys; };
+struct SortArgs {
+    const int32_t* ids; int B, F; int64_t n_rows; int4* rec; int* owner_cnt; int nblk; void* skeys;
+    // bag mode only (null otherwise): which rows of this batch sit in MORE THAN ONE column.  The grouping is per column, and a
+    // row's update is one read-modify-write per column segment -- two columns holding the same row (python/SNN_RBM.py:248-253
+    // lists a line's active features in line order, so a feature's column depends on the line) would race.  Every segment head
+    // claims its row with atomicMax(tag_first[row], stamp << 6 | column); a head that finds this batch's stamp already there
+    // under another column marks tag_shared[row] = stamp, and the update launches (at least one kernel boundary later) add
+    // into such rows with float atomics instead (scatw1_body / scatw2_body).  Stamps grow with every grouping: no reset pass.
+    int* tag_first; int* tag_shared; int stamp;
+};
 
 constexpr int SORT_N = 4096;     // keys per field handled by the union-kernel path (B <= 4096)
 
@@ -138,7 +147,14 @@ __device__ __forceinline__ void sortB_body(const SortArgs& so, const int blk, un
         e += be[r] - r * 256 + (s_key[be[r]] < hi_key ? 1 : 0);
     }
     int4 rr = make_int4(-1, 0, 0, 0);
-    if (row != inv_row<KT>()) rr = make_int4((int)row, (int)(key & (((KT)1 << SH) - 1)), s, e);
+    if (row != inv_row<KT>()) {
+        rr = make_int4((int)row, (int)(key & (((KT)1 << SH) - 1)), s, e);
+        if (so.tag_first && pos == s) {                            // head of its segment: one claim per (row, column)
+            const int mine = (so.stamp << 6) | f;
+            const int old = atomicMax(&so.tag_first[(size_t)row], mine);
+            if ((old >> 6) == so.stamp && old != mine) so.tag_shared[(size_t)row] = so.stamp;
+        }
+    }
     so.rec[(size_t)f * SORT_N + pos] = rr;
 }
 

@@ -333,6 +333,13 @@ int ctr_count_lines(const char* path, int n_threads, int64_t* n_lines, int64_t* 
 int ctr_parse_examples(const char* path, int mode, const ctr_fm_model* m, int width, int n_threads, int64_t cap,
                        int32_t* ids_out, int32_t* vals_out, int32_t* y_out, int64_t* n_out)
 {
+    return ctr_parse_examples_ex(path, mode, m, width, n_threads, cap, ids_out, vals_out, y_out, n_out, 0, nullptr, nullptr);
+}
+
+int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int width, int n_threads, int64_t cap,
+                          int32_t* ids_out, int32_t* vals_out, int32_t* y_out, int64_t* n_out,
+                          int64_t shadow_cap, int32_t* shadow_out, int64_t* n_shadow)
+{
     if (!path || !ids_out || !y_out || !n_out || width < 1 || cap < 0) return fail(CTR_ERR_ARG, "null / bad argument");
     if (mode < CTR_MODE_FNN || mode > CTR_MODE_PAIRS) return fail(CTR_ERR_ARG, "bad mode");
     if (mode == CTR_MODE_FNN && (!m || width != m->n_fields)) return fail(CTR_ERR_ARG, "CTR_MODE_FNN needs the FM model and width == its n_fields");
@@ -346,9 +353,13 @@ int ctr_parse_examples(const char* path, int mode, const ctr_fm_model* m, int wi
     const int64_t total = rs.back().ex0 + rs.back().examples;
     if (total > cap) return fail(CTR_ERR_CAP, std::string(path) + ": " + std::to_string(total) + " examples, room for " + std::to_string(cap));
     Err err;
+    if (n_shadow) *n_shadow = 0;
+    if (shadow_cap < 0 || (shadow_cap > 0 && !shadow_out)) return fail(CTR_ERR_ARG, "shadow_cap without shadow_out");
+    std::vector<std::vector<int64_t>> shadows(rs.size());      // per range, (example, field, row) in line order
     run_threads((int)rs.size(), [&](int t) {
         const Range& r = rs[t];
         std::vector<Tok> tok;
+        std::vector<int64_t>& sh = shadows[t];
         size_t s = r.lo, e, nx; int64_t ln = r.line0 + 1, ex = r.ex0;
         for (; s < r.hi; s = nx, ++ln) {
             line_end(f.p, f.n, s, e, nx);
@@ -367,7 +378,11 @@ int ctr_parse_examples(const char* path, int mode, const ctr_fm_model* m, int wi
                     if (!py_int(tok[j].b, tok[j].e, feat)) { err.set(ln, CTR_ERR_PARSE, "feature id is not an int"); return; }
                     const int32_t rr = m->map.get(feat);
                     if (rr < 0) { err.set(ln, CTR_ERR_KEY, "feature " + std::to_string(feat) + " is not in the FM model (KeyError)"); return; }
-                    row[m->field[rr]] = rr;
+                    int32_t& slot = row[m->field[rr]];
+                    // an earlier feature of the same field: the gather forgets it (the later one wins, data_fm.py:52-53), the
+                    // update loop does not (python/FNN_wnzh.py:300-306 walks every feature of the line)
+                    if (slot >= 0) { sh.push_back(ex); sh.push_back(m->field[rr]); sh.push_back(slot); }
+                    slot = rr;
                 }
             } else {
                 if ((tok.size() & 1) == 0) { err.set(ln, CTR_ERR_PARSE, "id without a value (IndexError)"); return; }
@@ -389,6 +404,18 @@ int ctr_parse_examples(const char* path, int mode, const ctr_fm_model* m, int wi
     });
     if (err.code != CTR_OK) return fail(err.code, std::string(path) + ":" + std::to_string(err.line.load()) + ": " + err.msg);
     *n_out = total;
+    int64_t ns = 0;
+    for (auto& sh : shadows) ns += (int64_t)sh.size() / 3;
+    if (n_shadow) *n_shadow = ns;
+    if (shadow_out) {
+        if (ns > shadow_cap) return fail(CTR_ERR_CAP, std::string(path) + ": " + std::to_string(ns) + " shadowed features, room for " + std::to_string(shadow_cap));
+        int64_t o = 0;
+        for (auto& sh : shadows)                                 // ranges are in file order
+            for (size_t i = 0; i < sh.size(); i += 3) {
+                if (sh[i] > INT32_MAX) return fail(CTR_ERR_CAP, "example index of a shadowed feature does not fit int32");
+                shadow_out[o++] = (int32_t)sh[i]; shadow_out[o++] = (int32_t)sh[i + 1]; shadow_out[o++] = (int32_t)sh[i + 2];
+            }
+    }
     return CTR_OK;
 }
 

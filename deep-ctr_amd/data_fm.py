@@ -117,12 +117,30 @@ class DataFM(object):
         ids = numpy.asarray(ids, dtype=numpy.int32).reshape(len(ys), len(self.name_field))
         return farray, ids, numpy.asarray(ys, dtype=numpy.int32)
 
-    def load_ids(self, file):
+    def load_ids(self, file, want_shadowed=False):
         """Whole file -> (ids int32 [N,16], y int32 [N]); blank lines skipped.  One native pass
-        (ctr_parse_examples, CTR_MODE_FNN) instead of get_fxy per line per epoch."""
+        (ctr_parse_examples, CTR_MODE_FNN) instead of get_fxy per line per epoch.  want_shadowed: also int32 [n, 3] =
+        (example, field, row) of the features a later feature of the same field shadows (see shadowed_of)."""
         from . import ingest
+        if want_shadowed:
+            ids, _, y, sh = ingest.parse_examples(file, ingest.MODE_FNN, self.model, len(self.name_field), want_shadowed=True)
+            return ids, y, sh
         ids, _, y = ingest.parse_examples(file, ingest.MODE_FNN, self.model, len(self.name_field))
         return ids, y
+
+    def shadowed_of(self, feats_per_example):
+        """(example, field, row) int32 [n, 3] of every feature of the given lines (lists of feature ids, as get_batch_ids
+        returns them) that a later feature of the same field overwrites in feats_to_ids: the reference's update loop visits
+        them all the same (python/FNN_wnzh.py:300-306) -- FNNEngine.set_shadowed carries them into the next train step."""
+        out = []
+        for t, feats in enumerate(feats_per_example):
+            seen = {}
+            for feat in feats:
+                fld = self.feat_field[feat]
+                if fld in seen:
+                    out.append((t, fld, seen[fld]))
+                seen[fld] = self.feat_row[feat]
+        return numpy.asarray(out, dtype=numpy.int32).reshape(len(out), 3)
 
     def table(self):
         """(rows float32 [D,K], field_of_row int32 [D], w_0) for FNNEngine.set_table."""

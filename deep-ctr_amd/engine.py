@@ -194,6 +194,14 @@ class FNNEngine(object):
             out['gx'] = gx
         return out
 
+    def set_shadowed(self, tfr):
+        """fnn_set_shadowed: int32 [n, 3] = (example t, field, row) of the features that a later feature of the same field
+        shadows in the NEXT train_step / step_begin batch; their rows take the sparse update too, as in the reference's loop
+        over every feature of a line (python/FNN_wnzh.py:300-306)."""
+        a = np.ascontiguousarray(tfr, dtype=np.int32).reshape(-1, 3)
+        self._enter()
+        self._ck(self.lib.fnn_set_shadowed(self.h, a.ctypes.data if len(a) else None, len(a), _capi.FNN_MEM_HOST))
+
     def prefetch_ids(self, ids_t):
         """Scheduling hint: start grouping the ids of an upcoming batch (a device int32 tensor that
         will be passed unchanged to train_step / step_begin)."""

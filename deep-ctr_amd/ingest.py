@@ -88,19 +88,36 @@ def count_lines(path, threads=None):
     return nl.value, ne.value
 
 
-def parse_examples(path, mode, model=None, width=16, threads=None):
-    """Whole file -> (ids int32 [N, width], vals int32 [N, width] or None, y int32 [N])."""
+def parse_examples(path, mode, model=None, width=16, threads=None, want_shadowed=False):
+    """Whole file -> (ids int32 [N, width], vals int32 [N, width] or None, y int32 [N]); want_shadowed (MODE_FNN): also the
+    features a later feature of their field replaced in `ids`, int32 [n, 3] = (example, field, row) in file order
+    (ctr_parse_examples_ex; the reference's update loop still visits them, python/FNN_wnzh.py:300-306)."""
     lib = _capi.load()
     threads = threads or n_threads()
     _, n = count_lines(path, threads)
     ids = np.empty((n, width), np.int32)
     vals = np.empty((n, width), np.int32) if mode == MODE_PAIRS else None
     y = np.empty(n, np.int32)
-    got = C.c_int64()
-    _ck(lib, lib.ctr_parse_examples(os.fsencode(path), mode, model.h if model is not None else None, width, threads, n,
-                                    ids.ctypes.data, vals.ctypes.data if vals is not None else None, y.ctypes.data, C.byref(got)))
+    got, nsh = C.c_int64(), C.c_int64()
+    cap = 1024 if want_shadowed else 0
+    while True:
+        sh = np.empty((cap, 3), np.int32)
+        rc = lib.ctr_parse_examples_ex(os.fsencode(path), mode, model.h if model is not None else None, width, threads, n,
+                                       ids.ctypes.data, vals.ctypes.data if vals is not None else None, y.ctypes.data, C.byref(got),
+                                       cap, sh.ctypes.data if want_shadowed else None, C.byref(nsh))
+        if want_shadowed and rc == _capi_err_cap() and nsh.value > cap:        # rare: lines with several features per field
+            cap = int(nsh.value)
+            continue
+        _ck(lib, rc)
+        break
     assert got.value == n
+    if want_shadowed:
+        return ids, vals, y, sh[:nsh.value].copy()
     return ids, vals, y
+
+
+def _capi_err_cap():
+    return -5          # CTR_ERR_CAP (include/ctr_ingest.h)
 
 
 def yzx_stat(path, threads=None):

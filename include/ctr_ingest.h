@@ -69,6 +69,14 @@ int ctr_count_lines(const char* path, int n_threads, int64_t* n_lines, int64_t* 
 int ctr_parse_examples(const char* path, int mode, const ctr_fm_model* m, int width, int n_threads,
                        int64_t cap, int32_t* ids_out, int32_t* vals_out, int32_t* y_out, int64_t* n_out);
 
+/* The same, also reporting what CTR_MODE_FNN's "later id of a field wins" drops: shadow_out [shadow_cap][3] int32 =
+ * (example, field, row) of every feature that a later feature of the same field replaced in ids_out, in file order
+ * (python/FNN_wnzh.py:300-306 still updates those rows: see fnn_set_shadowed in fnn_hip.h).  *n_shadow = how many there are
+ * (written also when shadow_out is NULL: count first, or retry after CTR_ERR_CAP). */
+int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int width, int n_threads,
+                          int64_t cap, int32_t* ids_out, int32_t* vals_out, int32_t* y_out, int64_t* n_out,
+                          int64_t shadow_cap, int32_t* shadow_out, int64_t* n_shadow);
+
 /* ---- A12: yzx ----------------------------------------------------------------------------------- */
 /* stat(): max index and max number of features per line over tokens 2.. (python/ipinyou.py:23-39). */
 int ctr_yzx_stat(const char* path, int n_threads, int64_t* n_examples, int64_t* max_dim, int64_t* max_fea);

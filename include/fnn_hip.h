@@ -80,7 +80,8 @@ typedef struct fnn_cfg {
     void*   stream;       /* hipStream_t to run on, or NULL = create one      */
     int32_t mode;         /* FNN_MODE_FM (FNN) or FNN_MODE_BAG (SNN fine-tune) */
     int32_t h0;           /* FNN_MODE_BAG: width of the bag rows / of x
-                             (hidden0, python/SNN_RBM.py:25,53); multiple of 4 */
+                             (hidden0, python/SNN_RBM.py:25,53: 300, or 200 for advertiser
+                             2997); a multiple of 4 in [192, 316] */
 } fnn_cfg;
 
 typedef struct fnn_handle fnn_handle;
@@ -130,6 +131,14 @@ int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memki
 int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B,
                    const uint8_t* mask1, const uint8_t* mask2, int b_size,
                    float* p_out, float* gx_out, int memkind, float* loss_sum_out);
+
+/* Features that a LATER feature of the same field shadows in the gather of the NEXT fnn_train_step / fnn_step_begin call.
+ * The layer-one array keeps one feature per field, the last of the line (python/FNN_wnzh.py:91-96), which is what
+ * ids [B, F] expresses; the reference's update loop nevertheless walks EVERY feature of the line (:300-306), so a shadowed
+ * feature's row also takes `row * c - lr * gx[t][1 + field*K + l]`.  tfr [n][3] int32 = (example t in [0, B), field, row),
+ * in any order; consumed by the next step (n = 0 clears).  FNN_MODE_FM; not combined with FNN_DP_SPARSE_EXCHANGE.  Such
+ * steps take the layer-by-layer kernels (B + n <= 16384).  iPinYou lines hold one feature per field: n = 0 there. */
+int fnn_set_shadowed(fnn_handle* h, const int32_t* tfr, int n, int memkind);
 
 /* Optional: hand the ids of an UPCOMING training batch to the library (DEVICE pointer, same
  * pointer and B as the later fnn_train_step / fnn_step_begin call).  The sparse-row update first

@@ -236,6 +236,39 @@ def scatter_sgd(rows, ids, gx, lr, lambda_fm, b_size=None):
     return rows
 
 
+def scatter_sgd_feats(rows, feats, row_of, field_of, gx, lr, lambda_fm, b_size=None):
+    """python/FNN_wnzh.py:299-306 on the reference's own data structure: `feats[t]` is the list of feature ids of line t
+    IN LINE ORDER (what get_batch_data returns as `f`), every one of which is visited -- also a feature that a later
+    feature of the same field has shadowed in the layer-one array (:91-96 keeps the last), and a feature listed twice:
+        for t: for feat in f[t]: for l: w[feat][l] = w[feat][l] * (1 - 2 lambda_fm lr / b_size) - lr * gx[t][1 + field(feat) k + l]
+    row_of / field_of: feature id -> row of `rows` / field index.  In place on rows [D, K]."""
+    K = rows.shape[1]
+    if b_size is None:
+        b_size = len(feats)
+    c = (1 - 2. * lambda_fm * lr / b_size)
+    for t in range(len(feats)):
+        gxt = gx[t]
+        for feat in feats[t]:
+            r, fld = row_of[feat], field_of[feat]
+            for l in range(K):
+                rows[r][l] = rows[r][l] * c - lr * gxt[1 + fld * K + l] * 1
+    return rows
+
+
+def train_step_feats(p, rows, w_0, feats, row_of, field_of, n_fields, y, r1, r2, lr, lambda1, lambda_fm,
+                     acti_type='tanh', b_size=None):
+    """The hot loop body (python/FNN_wnzh.py:296-306) on feature lists: gather with "last feature of a field wins"
+    (:91-96), train, then the update loop over EVERY listed feature.  Mutates p and rows."""
+    ids = np.full((len(feats), n_fields), -1, dtype=np.int64)
+    for t, ft in enumerate(feats):
+        for feat in ft:
+            ids[t, field_of[feat]] = row_of[feat]
+    x = gather(rows, ids, w_0)
+    gx, pre, loss, p_drop, g = train_call(p, x, y, r1, r2, lr, lambda1, acti_type)
+    scatter_sgd_feats(rows, feats, row_of, field_of, gx, lr, lambda_fm, b_size)
+    return {'x': x, 'gx': gx, 'loss': loss, 'p_drop': p_drop, 'grads': g, 'pre': pre, 'ids': ids}
+
+
 def scatter_sgd_closed_form(rows, ids, gx, lr, lambda_fm, b_size=None):
     """Closed form of A6 used to cross-check it: a row hit by m slot-grads g_1..g_m
     (in example order) ends at row*c^m - lr*sum_j g_j*c^(m-j)."""

@@ -231,6 +231,79 @@ def test_virtual_two_rank_exchange_mode_equals_single_gpu_tables(built):
         e.close()
 
 
+@pytest.mark.parametrize("B,prec", [(64, 'f32'), (700, 'f32'), (4096, 'f32'), (700, 'bf16')])
+def test_two_features_of_one_field_both_rows_are_updated(built, B, prec):
+    """python/FNN_wnzh.py:300-306 walks EVERY feature of a line: a feature that a later feature of the same field shadows
+    in the layer-one array (:91-96) still takes `row * c - lr * gx[slot]`, and a feature listed twice takes it twice.  The
+    lines here hold up to three features of a field (fnn_set_shadowed carries the shadowed ones); reference: the oracle's
+    loop over feature lists, two steps in a row, the second without shadowed features (the list is consumed)."""
+    rng = np.random.RandomState(B)
+    sizes = synth.field_sizes_tiny(1000)
+    offs = np.cumsum([0] + sizes[:-1])
+    rows = synth.fm_table(sum(sizes), K, 0.05, 3)
+    fo = synth.field_of_row(sizes)
+    _, _, _, _, p, r1, r2 = make_problem(8, seed=B)
+    feats = []                                              # feature id == row id here
+    for t in range(B):
+        ft = []
+        for f in range(F):
+            n = 1 if rng.uniform() < 0.8 else int(rng.randint(0, 4))     # 0..3 features of this field
+            pick = list(offs[f] + rng.randint(0, min(sizes[f], 5), size=n))   # few distinct rows: many repeats across examples
+            if n == 3 and rng.uniform() < 0.5:
+                pick[2] = pick[0]                                            # the same feature twice in one line
+            ft += pick
+        rng.shuffle(ft)
+        feats.append([int(v) for v in ft])
+    ident = {int(r): int(r) for r in range(rows.shape[0])}
+    field_of = {int(r): int(fo[r]) for r in range(rows.shape[0])}
+    y = (rng.uniform(size=B) < 0.3).astype(np.float32)
+    lr, lam1, lamfm = 0.01, 0.0, 0.1
+    rows64 = rows.astype(np.float64)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ref = orc.train_step_feats(p64, rows64, -3.0, feats, ident, field_of, F, y.astype(np.float64), r1.astype(float), r2.astype(float),
+                               lr, lam1, lamfm)
+    ids = ref['ids'].astype(np.int32)
+    shadow = []
+    for t, ft in enumerate(feats):
+        seen = {}
+        for feat in ft:
+            if field_of[feat] in seen:
+                shadow.append((t, field_of[feat], seen[field_of[feat]]))
+            seen[field_of[feat]] = feat
+    assert len(shadow) > B // 20
+    eng = make_engine(rows, fo, p, prec=prec, lr=lr, lam1=lam1, lamfm=lamfm)
+    eng.set_shadowed(np.asarray(shadow, np.int32))
+    out = eng.train_step(ids, y, r1, r2, want_gx=True)
+    got = eng.get_table()
+    change = np.abs(rows64 - rows).max()
+    tol = 3e-4 if prec == 'f32' else 8e-2
+    assert np.abs(got - rows64).max() <= tol * change + 2e-7
+    if prec == 'f32':
+        assert abs(out['loss'] - ref['loss']) <= 2e-5 * abs(ref['loss'])
+        # rows that ONLY shadowed features touch moved too (the round-1 path left them alone)
+        main_rows = set(int(v) for v in ids[ids >= 0])
+        only_shadow = np.array(sorted(set(s[2] for s in shadow) - main_rows))
+        assert len(only_shadow) > 0 and np.all(np.abs(got[only_shadow] - rows[only_shadow]).max(axis=1) > 0)
+    # second step, no shadowed features announced: the plain update again
+    ids_b = synth.zipf_ids(B, sizes, 1.1, 9)
+    eng.train_step(ids_b, y, r1, r2)
+    orc.train_step(p64, rows64, -3.0, ids_b, y.astype(np.float64), r1.astype(float), r2.astype(float), lr, lam1, lamfm)
+    change = np.abs(rows64 - rows).max()
+    assert np.abs(eng.get_table() - rows64).max() <= tol * change + 2e-7
+    eng.close()
+
+
+def test_shadowed_list_is_validated(built):
+    rows, fo, ids, y, p, r1, r2 = make_problem(32, seed=4)
+    eng = make_engine(rows, fo, p)
+    eng.set_shadowed(np.array([[40, 0, 1]], np.int32))          # example 40 of a batch of 32
+    eng.train_step(ids, y, r1, r2, want_loss=False)
+    with pytest.raises(FNNError) as e:
+        eng.sync()
+    assert e.value.code == _capi.FNN_ERR_RANGE
+    eng.close()
+
+
 def test_prefetch_ids_changes_nothing(built):
     """fnn_prefetch_ids is a scheduling hint: with or without it the state after several steps is
     bitwise identical (and so is a run where the hint named a batch that never came)."""
@@ -558,12 +631,18 @@ def make_snn_engine(ww0, bb0, p, prec='f32', lr=0.01, lam1=0.001, h0=200):
     return eng
 
 
-@pytest.mark.parametrize("B,kw", [(1, {}), (37, {"empty": [(3, 2)]}), (300, {"dup_col": 6}), (1000, {})])
+@pytest.mark.parametrize("B,kw", [(1, {}), (37, {"empty": [(3, 2)]}), (300, {"dup_col": 6}), (1000, {}),
+                                  # hidden0 = 300, the reference's default for every advertiser but 2997 (python/SNN_RBM.py:25): bag rows
+                                  # padded to 320 floats, the CX = 5 instance of the strip kernel; 256 and 316 are that instance's edges
+                                  (1, {"h0": 300}), (300, {"h0": 300, "dup_col": 6, "empty": [(5, 0)]}), (1000, {"h0": 300}),
+                                  (130, {"h0": 256}), (130, {"h0": 316}), (130, {"h0": 252}), (130, {"h0": 192})])
 def test_snn_step_f32_vs_oracle(built, B, kw):
     """A8: bag + sigmoid gather, MLP with L2 on all six tensors, per-example row updates without
     decay (python/SNN_RBM.py:238-291) against the float64 oracle."""
-    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(B, seed=B, **kw)
-    eng = make_snn_engine(ww0, bb0, p)
+    kw = dict(kw)
+    h0 = kw.pop("h0", 200)
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(B, seed=B, h0=h0, **kw)
+    eng = make_snn_engine(ww0, bb0, p, h0=h0)
     x = eng.gather(ids).cpu().numpy()
     ww64, bb64 = ww0.astype(np.float64), bb0.astype(np.float64)
     np.testing.assert_allclose(x, orc.snn_bag(ww64, bb64, ids), rtol=2e-6, atol=1e-7)
@@ -585,6 +664,55 @@ def test_snn_step_f32_vs_oracle(built, B, kw):
         assert np.abs(d[k] - p64[k]).max() <= 1e-3 * scale + 1e-7, k
     pr = eng.predict(ids).cpu().numpy()
     np.testing.assert_allclose(pr, orc.snn_predict(p64, ww64, bb64, ids), rtol=3e-4, atol=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_snn_same_row_in_several_columns(built, prefetch, tmp_path):
+    """python/SNN_RBM.py:248-253 lists a line's ACTIVE features in line order, so a feature's column depends on the line: a
+    token with value != 1 shifts everything behind it, and a feature may be listed twice.  The update of a row is grouped per
+    column; rows that several columns of a batch hold must still receive every occurrence's delta (round-1 advisor finding:
+    lost updates).  Lines go through the native SNN reader; two steps, the second one grouped ahead (fnn_prefetch_ids)."""
+    import torch
+    from deep_ctr_amd import ingest
+    rng = np.random.RandomState(17)
+    B, n_rows, h0 = 600, 400, 200
+    lines = []
+    for t in range(2 * B):
+        feats = list(rng.randint(0, n_rows, size=16))
+        if t % 3 == 0:
+            feats[5] = feats[1]                                   # the same feature twice on the line
+        vals = [1] * 16
+        for j in rng.choice(16, size=rng.randint(0, 4), replace=False):
+            vals[j] = int(rng.choice([0, 2]))                     # inactive: everything behind it moves one column left
+        lines.append('%d %s' % (rng.randint(0, 2), ' '.join('%d:%d' % (f, v) for f, v in zip(feats, vals))))
+    path = tmp_path / 'train.fm.txt'
+    path.write_text('\n'.join(lines) + '\n')
+    ids, _, yi = ingest.parse_examples(str(path), ingest.MODE_SNN_ACTIVE, None, 16)
+    # the same row does sit in different columns, across examples and inside one
+    cols = {}
+    for t in range(B):
+        for f in range(16):
+            if ids[t, f] >= 0:
+                cols.setdefault(int(ids[t, f]), set()).add(f)
+    assert sum(len(c) > 1 for c in cols.values()) > 100
+    ww0, bb0, _, _, p, r1, r2 = make_snn_problem(8, n_rows=n_rows, seed=3, h0=h0)
+    ww0 = ww0[:n_rows].copy()
+    y = yi.astype(np.float32)
+    eng = make_snn_engine(ww0, bb0, p, h0=h0)
+    ww64, bb64 = ww0.astype(np.float64), bb0.astype(np.float64)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    dev_ids = [torch.as_tensor(np.ascontiguousarray(ids[s * B:(s + 1) * B])).cuda() for s in range(2)]
+    for s in range(2):
+        sl = slice(s * B, (s + 1) * B)
+        if prefetch and s == 0:
+            eng.prefetch_ids(dev_ids[1])
+        out = eng.train_step(dev_ids[s], y[sl], r1, r2)
+        ref = orc.snn_train_step(p64, ww64, bb64, ids[sl], y[sl].astype(np.float64), r1.astype(float), r2.astype(float), 0.01, 0.001)
+        assert abs(out['loss'] - ref['loss']) <= 5e-5 * max(1.0, abs(ref['loss']))
+    upd = np.abs(ww64 - ww0).max()
+    assert np.abs(eng.get_table() - ww64).max() <= 1e-3 * upd + 3e-7
+    assert np.abs(eng.get_bag_bias() - bb64).max() <= 1e-3 * np.abs(bb64 - bb0).max() + 3e-7
     eng.close()
 
 
@@ -625,9 +753,10 @@ def test_virtual_two_rank_dp_bag_mode(built):
         e.close()
 
 
-def test_snn_step_bf16_tracks_oracle(built):
-    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(512, seed=5, dup_col=3)
-    eng = make_snn_engine(ww0, bb0, p, prec='bf16')
+@pytest.mark.parametrize("h0", [200, 300])
+def test_snn_step_bf16_tracks_oracle(built, h0):
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(512, seed=5, dup_col=3, h0=h0)
+    eng = make_snn_engine(ww0, bb0, p, prec='bf16', h0=h0)
     out = eng.train_step(ids, y, r1, r2, want_p=True)
     ww64, bb64 = ww0.astype(np.float64), bb0.astype(np.float64)
     ref = orc.snn_train_step(p, ww64, bb64, ids, y.astype(np.float64), r1.astype(float), r2.astype(float), 0.01, 0.001)

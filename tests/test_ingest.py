@@ -88,6 +88,11 @@ def test_edge_cases_of_the_model_and_example_parsers(built, tmp_path):
     rid, ry = io.fnn_examples(str(ep), ff, feat_row)
     assert np.array_equal(ids, rid) and np.array_equal(y, ry) and len(y) == 4
     assert ids[1, 3] == feat_row[12] and ingest.count_lines(str(ep)) == (6, 4)
+    # what "the later one wins" drops is reported for the update loop, which visits every feature (python/FNN_wnzh.py:300-306)
+    for threads in (1, 3):
+        ids2, _, y2, sh = ingest.parse_examples(str(ep), ingest.MODE_FNN, m, 16, threads=threads, want_shadowed=True)
+        assert np.array_equal(ids2, rid) and np.array_equal(y2, ry)
+        assert sh.tolist() == [[1, 3, feat_row[13]]]
     # the SNN readers split on single spaces: line 5 is a ValueError there, as in the reference
     with pytest.raises(ValueError, match=r'train\.fm\.txt:5'):
         ingest.parse_examples(str(ep), ingest.MODE_SNN_ACTIVE, None, 16)
@@ -103,6 +108,36 @@ def test_edge_cases_of_the_model_and_example_parsers(built, tmp_path):
     assert np.array_equal(pi, ri) and np.array_equal(pv, rv)
     with pytest.raises(IndexError):                         # more features than the row is wide
         ingest.parse_examples(str(sp), ingest.MODE_PAIRS, None, 2)
+
+
+def test_shadowed_features_many_lines_and_the_python_side(built, tmp_path):
+    """Lines with two or three features of one field, and one feature twice: the native parser's shadow list equals what
+    DataFM.shadowed_of derives from the reference-style feature lists, in file order, for any thread count and any
+    initial capacity (the retry after CTR_ERR_CAP)."""
+    from deep_ctr_amd.data_fm import DataFM
+    mp = tmp_path / 'fm.model.txt'
+    feats = list(range(100, 160))
+    fld = [i % 16 for i in range(60)]
+    with open(mp, 'w') as f:
+        f.write('-1.5 60 2\n')
+        for ft, fl in zip(feats, fld):
+            f.write('%d 0.1 0.2 0.3 %s:%d\n' % (ft, NAMES[fl], ft))
+    rng = np.random.RandomState(3)
+    lines, ref_lists = [], []
+    for t in range(3000):
+        ft = list(rng.choice(feats, size=rng.randint(1, 20)))
+        lines.append('%d %s' % (t % 2, ' '.join('%d:1' % v for v in ft)))
+        ref_lists.append(ft)
+    ep = tmp_path / 'train.fm.txt'
+    ep.write_text('\n'.join(lines) + '\n')
+    data = DataFM(str(mp))
+    want = data.shadowed_of(ref_lists)
+    assert len(want) > 1024                                   # beyond the first capacity guess
+    for threads in (1, 4):
+        ids, y, sh = data.load_ids(str(ep), want_shadowed=True) if threads == 4 else \
+            (lambda r: (r[0], r[2], r[3]))(ingest.parse_examples(str(ep), ingest.MODE_FNN, data.model, 16, threads=1, want_shadowed=True))
+        assert np.array_equal(sh, want)
+        assert np.array_equal(ids, np.stack([data.feats_to_ids(ft) for ft in ref_lists]))
 
 
 def test_errors_keep_the_reference_exception_and_name_the_first_bad_line(built, tmp_path):

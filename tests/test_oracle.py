@@ -437,3 +437,29 @@ def test_more_golden_vectors_reproduce(golden_dir):
     _, z1 = ipo.z1_of(g['table'], params['b'], g['ids'])
     np.testing.assert_allclose(z1, g['z1'], rtol=0, atol=1e-15)
     np.testing.assert_allclose(ipo.predict(params, g['table'], g['ids'], 'relu'), 1 / (1 + np.exp(-g['logits'])), rtol=1e-12)
+
+
+def test_scatter_over_feature_lists_reduces_to_the_id_matrix_form():
+    """With one feature per field the reference's loop over feature lists (scatter_sgd_feats) IS scatter_sgd on the id
+    matrix; with a shadowed or repeated feature it visits more rows / visits a row twice (python/FNN_wnzh.py:300-306)."""
+    rng = np.random.RandomState(0)
+    F, K, B = 4, 3, 50
+    sizes = [3, 5, 2, 6]
+    offs = np.cumsum([0] + sizes[:-1])
+    rows = rng.standard_normal((sum(sizes), K))
+    ids = np.stack([offs[f] + rng.randint(0, sizes[f], size=B) for f in range(F)], axis=1)
+    gx = rng.standard_normal((B, 1 + F * K))
+    field_of = {int(r): int(np.searchsorted(offs, r, side='right') - 1) for r in range(sum(sizes))}
+    ident = {r: r for r in field_of}
+    a, b = rows.copy(), rows.copy()
+    orc.scatter_sgd(a, ids, gx, 0.1, 0.3)
+    orc.scatter_sgd_feats(b, [list(map(int, ids[t])) for t in range(B)], ident, field_of, gx, 0.1, 0.3)
+    assert np.array_equal(a, b)
+    # one line, field 1 holds features 3 then 4 (4 wins the gather), feature 0 twice: rows 3 and 4 both move, row 0 twice
+    c = 1 - 2 * 0.3 * 0.1 / 1
+    r = rows.copy()
+    orc.scatter_sgd_feats(r, [[0, 3, 4, 0]], ident, field_of, gx[:1], 0.1, 0.3, b_size=1)
+    g0, g1 = gx[0, 1:1 + K], gx[0, 1 + K:1 + 2 * K]
+    np.testing.assert_allclose(r[3], rows[3] * c - 0.1 * g1, rtol=1e-14)
+    np.testing.assert_allclose(r[4], rows[4] * c - 0.1 * g1, rtol=1e-14)
+    np.testing.assert_allclose(r[0], (rows[0] * c - 0.1 * g0) * c - 0.1 * g0, rtol=1e-14)
