@@ -351,12 +351,28 @@ template <typename T> struct EpiIpBwd {      // delta l_t = (delta l_{t+1} W^T) 
 // reads every weight once per pass: 16 RT FLOP per L2 byte, which is what bounds these kernels.
 // ------------------------------------------------------------------------------------------
 constexpr int STRIP_MAXP = IPNN_MAX_HIDDEN + 1;                  // products of the stack
+// TWO workgroups per strip (h = blockIdx.x & 1; strip = blockIdx.x >> 1): a 32-example strip occupies one CU and at batch 4096
+// that is 128 of the chip's 256, each streaming every weight at the ~75 GB/s one CU draws from L2 -- the bound of these kernels.
+// The pair splits every WIDE product by output column blocks (block j belongs to workgroup j & 1), so each CU streams half the
+// weights, and swaps halves after it: a workgroup pushes its blocks of the new activation tile to `xch` with write-through
+// (sc1) 8-byte stores, drains them, raises its flag, polls its partner's and pulls the partner's blocks into its own LDS tile
+// with sc1 loads (MI355X_MICROARCH.md, "Valid forms": every store and load of the handed-off bytes sc1, stores drained before
+// the flag, one lane polls, the others load behind a workgroup barrier).  Narrow products (fewer than DUO_MIN_BLOCKS column
+// blocks) are computed by BOTH workgroups -- their weights are a few hundred KB, a swap costs more -- and workgroup 0 alone
+// writes their outputs.  Workgroups b and b + 8 share an XCD, so the even XCDs only ever stream the even blocks' weights and
+// the odd XCDs the odd ones: half the weight footprint per L2.  Flags hold launch_epoch * 16 + (swap index + 1): they only
+// grow, so nothing is reset between launches; a poll gives up after DUO_SPIN_LIMIT tries and raises `err` (no hang on a bug).
+struct StripDuo { int on; unsigned long long* xch; int* flags; int epoch; int* err; size_t xch_wg; };
+constexpr int DUO_MIN_BLOCKS = 5;
+constexpr int DUO_SPIN_LIMIT = 1 << 22;
 template <typename T> struct StripFwdArgs {
     const T* a0; int n;                                          // a0: F layout [Ba][Dp0]; n = L + 1
     const T* W[STRIP_MAXP]; int Dp[STRIP_MAXP + 1];              // W[t-1] = wf[t-1]: fragment-tiled [Dp_t][Dp_{t-1}]
     EpiIpFwd<T> ef[STRIP_MAXP]; EpiIpOut<T> eo;                  // ef[t-1], t = 1..L; eo: the output unit
     long long* dbg;                                              // IPNN_STAMPS=1 (diagnostics): s_memtime per layer, 16 per workgroup
     int rot;                                                     // rotate the block order per workgroup (IPNN_STRIP_ROT=0: off)
+    StripDuo duo;                                                // two workgroups per strip (see StripDuo); duo.on = 0: one
+    int sel;                                                     // IPNN_STAMPS: the product whose first block of wave 0 is stamped in detail (slots 10..14)
 };
 template <typename T> struct StripBwdArgs {
     const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
@@ -364,6 +380,7 @@ template <typename T> struct StripBwdArgs {
     EpiIpBwd<T> eb[STRIP_MAXP];                                  // eb[t-1]: product t -> delta l_{t-1}
     long long* dbg;
     int rot;
+    StripDuo duo;
 };
 
 // one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
@@ -490,22 +507,84 @@ template <typename T> __device__ __forceinline__ void strip_load(T* dst, const T
 
 #define STRIP_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 constexpr int STRIP_NW = 8;                                      // waves per strip workgroup (2 per SIMD: 256 registers each)
-// A wave's blocks of the stack in order: (product p, block w), (p, w + NW), ... then the next product it has a
+// A wave's blocks of the stack in order: (product p, list index w), (p, w + NW), ... then the next product it has a
 // block in.  The weights of the NEXT block are requested before the current block's epilogue (they do not
 // depend on the strip), so the barrier between two products and the epilogue hide their L2 round trip.
+// A workgroup's LIST of a product's column blocks: all nblk of them, or -- a wide product of a pair (StripDuo) -- the
+// (nblk - h + 1) / 2 blocks j with j & 1 == h.
 struct StripItem { int p, blk; };
-// Workgroups walk a product's column blocks in rotated order (logical block b of workgroup g is block (b + g) mod nblk), so
-// that the 16 workgroups of an XCD do not all stream the same weights -- the same L2 channels -- at the same moment.
-__device__ __forceinline__ int strip_phys(const int blk, const int nblk, const int rot) { return (blk + rot) % nblk; }
-template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd)
+__device__ __forceinline__ bool duo_split(const StripDuo& d, const int nblk) { return d.on && nblk >= DUO_MIN_BLOCKS; }
+__device__ __forceinline__ int duo_count(const bool split, const int nblk, const int h) { return split ? (nblk - h + 1) >> 1 : nblk; }
+// Workgroups walk their list in rotated order (list entry i of a workgroup with rotation g is entry (i + g) mod cnt), so
+// that the workgroups of an XCD do not all stream the same weights -- the same L2 channels -- at the same moment.
+__device__ __forceinline__ int strip_phys(const bool split, const int i, const int cnt, const int h, const int rot) {
+    const int r = (i + rot) % cnt;
+    return split ? 2 * r + h : r;
+}
+template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd, const int h)
 {   // fwd: product p has Dp[p + 1] / 64 blocks (the output unit, p = n - 1: one); bwd: product index q = n - t, Dp[t - 1] / 64 blocks
     it.blk += STRIP_NW;
     for (;;) {
         if (it.p >= a.n) return it;
         const int nblk = fwd ? a.Dp[it.p + 1] / 64 : a.Dp[a.n - it.p - 1] / 64;
-        if (it.blk < nblk) return it;
+        if (it.blk < duo_count(duo_split(a.duo, nblk), nblk, h)) return it;
         it.p += 1; it.blk = wave;
     }
+}
+
+// ---- the swap of a pair (StripDuo).  xch of workgroup (strip, h): [2 parities][own block r = j >> 1][RT][256] 8-byte words,
+// a block's RT x 2 KB in the order they have in the LDS tile (row tile m: k-steps 2 j and 2 j + 1 are adjacent there).
+template <typename T, int RT>
+__device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const int N, const int j, const int parity, const int lane)
+{   // by the wave that has just written block j of the tile `out` (LDS operations of one wave complete in order)
+    unsigned long long* dst = d.xch + (size_t)blockIdx.x * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + (size_t)(j >> 1) * (RT * 256);
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(out + ft_off<T>(m * 16, j * 64, N));
+        unsigned long long v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = src[lane + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + m * 256 + lane + 64 * q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+    }
+}
+// every wave has drained its pushes -> flag -> the partner's flag -> the partner's blocks into `out`.  `pull` = false: this
+// workgroup has nothing left to compute (it only publishes).  All 64 NW threads call it.
+template <typename T, int RT>
+__device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N, const int nblk, const int h, const int parity, const int seq,
+                                         const bool pull, long long* dbg)
+{
+    long long ta = 0, tb = 0;
+    if (dbg && threadIdx.x == 0) ta = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's sc1 stores have left (and whatever else it had in flight)
+    lds_barrier();
+    const int want = d.epoch * 16 + seq;
+    if (dbg && threadIdx.x == 0) { tb = (long long)__builtin_amdgcn_s_memtime(); dbg[11] += tb - ta; }    // drain + barrier
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(d.flags + blockIdx.x, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pull) {
+            int n = 0;
+            while (__hip_atomic_load(d.flags + (blockIdx.x ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++n > DUO_SPIN_LIMIT) { atomicOr(d.err, 2); break; }      // a partner that never arrives: report, do not hang
+            }
+        }
+    }
+    if (!pull) return;
+    lds_barrier();
+    if (dbg && threadIdx.x == 0) { ta = (long long)__builtin_amdgcn_s_memtime(); dbg[12] += ta - tb; }    // flag + the partner's
+    const int ph = h ^ 1, cntp = (nblk - ph + 1) >> 1, t = threadIdx.x, m = t >> 8, idx = t & 255;      // one 8-byte word per thread per block
+    const unsigned long long* src = d.xch + (size_t)(blockIdx.x ^ 1) * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + t;
+    for (int r0 = 0; r0 < cntp && t < RT * 256; r0 += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = r0 + k < cntp ? __hip_atomic_load(src + (size_t)(r0 + k) * (RT * 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (r0 + k < cntp) reinterpret_cast<unsigned long long*>(out + ft_off<T>(m * 16, (2 * (r0 + k) + ph) * 64, N))[idx] = v[k];
+    }
+    if (dbg && threadIdx.x == 0) dbg[13] += (long long)__builtin_amdgcn_s_memtime() - ta;                  // pull (thread 0's share)
 }
 
 template <typename T, int RT>
@@ -516,30 +595,52 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = blockIdx.x * RT * 16;
+    const int h = a.duo.on ? (int)(blockIdx.x & 1) : 0, sidx = a.duo.on ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int row0 = sidx * RT * 16;
     STRIP_STAMP(0);
+    if (a.dbg && threadIdx.x == 0) { for (int i = 10; i < 16; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = 0; }
     StripB<T> pb;
-    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, true);
-    const int rot = (a.rot == 1) ? (int)(blockIdx.x >> 3) : (a.rot == 2 ? (int)blockIdx.x : 0);   // workgroups g, g + 8, ... share an XCD
-    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(nx.blk, a.Dp[nx.p + 1] / 64, rot), lane);
-    // the strip of a0: row tiles RT blockIdx.x .. of an F-layout operand are contiguous
-    strip_load<T>(in, a.a0 + (size_t)blockIdx.x * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
+    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, true, h);
+    const int rot = (a.rot == 1) ? (sidx >> 3) : (a.rot == 2 ? sidx : 0);   // workgroups g, g + 8, ... share an XCD
+    // the last product this workgroup computes: the second of a pair stops behind the last product the pair splits
+    int last = a.n - 1;
+    if (h == 1) { last = -1; for (int p = 0; p < a.n; ++p) if (duo_split(a.duo, a.Dp[p + 1] / 64)) last = p; }
+    auto blocks = [&](const int p, bool& split, int& cnt) { const int nb = a.Dp[p + 1] / 64; split = duo_split(a.duo, nb); cnt = duo_count(split, nb, h); };
+    auto prefetch_next = [&]() {
+        if (nx.p < a.n && nx.p <= last) {
+            bool sp; int cn; blocks(nx.p, sp, cn);
+            strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+        }
+    };
+    prefetch_next();
+    // the strip of a0: row tiles RT sidx .. of an F-layout operand are contiguous
+    strip_load<T>(in, a.a0 + (size_t)sidx * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
     lds_barrier();
     STRIP_STAMP(1);
     f32x4 acc[RT][4];
-    for (int l = 0; l < a.n; ++l) {
+    int seq = 0;
+    for (int l = 0; l <= last; ++l) {
         const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
         const bool hidden = l + 1 < a.n;
+        bool split; int cnt; blocks(l, split, cnt);
         while (nx.p == l) {
-            const int blk = strip_phys(nx.blk, N / 64, rot);
+            const int blk = strip_phys(split, nx.blk, cnt, h, rot);
+            const bool det = a.dbg && l == a.sel && threadIdx.x == 0;
+#define DET(i) do { if (det) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+            DET(10);
             if (hidden) {
-                const EpiIpFwd<T> ef = a.ef[l];                 // the layer's epilogue parameters: scalar registers, loaded once
+                EpiIpFwd<T> ef = a.ef[l];                       // the layer's epilogue parameters: scalar registers, loaded once
+                if (a.duo.on && !split && h == 1) ef.outT = nullptr;     // (not reached: the second workgroup computes split products only)
                 typename EpiIpFwd<T>::Aux ax[RT][4];
                 strip_aux<T, RT>(ax, ef, row0, blk, lane);
                 strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
-                nx = strip_next(a, nx, wave, true);
-                if (nx.p < a.n) strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(nx.blk, a.Dp[nx.p + 1] / 64, rot), lane);
+                DET(11);
+                nx = strip_next(a, nx, wave, true, h);
+                prefetch_next();
+                DET(12);
                 strip_epilogue<T, RT>(acc, ax, ef, out, N, row0, blk, lane);
+                DET(13);
+                if (split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
             } else {                                              // the output unit: logits, loss, delta (column 0)
                 strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 nx.p = a.n;
@@ -560,6 +661,7 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 }
             }
         }
+        if (split) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (hidden) lds_barrier();
         STRIP_STAMP(2 + l);
         T* t = in; in = out; out = t;
@@ -574,28 +676,42 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = blockIdx.x * RT * 16;
+    const int h = a.duo.on ? (int)(blockIdx.x & 1) : 0, sidx = a.duo.on ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int row0 = sidx * RT * 16;
     STRIP_STAMP(0);
+    if (a.dbg && threadIdx.x == 0) { for (int i = 10; i < 16; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = 0; }
     StripB<T> pb;                                                 // item index q = n - t: product t = n - q
-    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false);
-    const int rot = (a.rot == 1) ? (int)(blockIdx.x >> 3) : (a.rot == 2 ? (int)blockIdx.x : 0);   // workgroups g, g + 8, ... share an XCD
-    if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(nx.blk, a.Dp[a.n - nx.p - 1] / 64, rot), lane);
-    strip_load<T>(in, a.dlast + (size_t)blockIdx.x * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
+    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false, h);
+    const int rot = (a.rot == 1) ? (sidx >> 3) : (a.rot == 2 ? sidx : 0);   // workgroups g, g + 8, ... share an XCD
+    auto blocks = [&](const int q, bool& split, int& cnt) { const int nb = a.Dp[a.n - q - 1] / 64; split = duo_split(a.duo, nb); cnt = duo_count(split, nb, h); };
+    auto prefetch_next = [&]() {
+        if (nx.p < a.n) {
+            bool sp; int cn; blocks(nx.p, sp, cn);
+            strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+        }
+    };
+    prefetch_next();
+    strip_load<T>(in, a.dlast + (size_t)sidx * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
     lds_barrier();
     STRIP_STAMP(1);
     f32x4 acc[RT][4];
+    int seq = 0;
     for (int t = a.n; t >= 1; --t) {                              // delta l_{t-1} = (delta l_t . W_t^T) * mask * act'
         const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
+        bool split; int cnt; blocks(q, split, cnt);
         while (nx.p == q) {
-            const int blk = strip_phys(nx.blk, N / 64, rot);
-            const EpiIpBwd<T> eb = a.eb[t - 1];
+            const int blk = strip_phys(split, nx.blk, cnt, h, rot);
+            EpiIpBwd<T> eb = a.eb[t - 1];
+            if (a.duo.on && !split && h == 1) { eb.outT = nullptr; eb.out32 = nullptr; }   // a narrow product of a pair: both compute it, the first one stores it
             typename EpiIpBwd<T>::Aux ax[RT][4];
             strip_aux<T, RT>(ax, eb, row0, blk, lane);
             strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
-            nx = strip_next(a, nx, wave, false);
-            if (nx.p < a.n) strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(nx.blk, a.Dp[a.n - nx.p - 1] / 64, rot), lane);
+            nx = strip_next(a, nx, wave, false, h);
+            prefetch_next();
             strip_epilogue<T, RT>(acc, ax, eb, t > 1 ? out : nullptr, N, row0, blk, lane);
+            if (split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
         }
+        if (split && t > 1) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (t > 1) lds_barrier();
         STRIP_STAMP(2 + q);
         T* x = in; in = out; out = x;
@@ -824,6 +940,8 @@ struct ipnn_handle {
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
+    int duo = 1;                                     // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo)
+    unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
 };
@@ -924,6 +1042,16 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     constexpr int RT = sizeof(T) == 2 ? 2 : 1;                   // strip = 32 (bf16) / 16 (f32) examples: two LDS tiles of 64 KiB at 1024 units
     const size_t strip_lds = (size_t)2 * RT * 16 * maxD * sizeof(T);
     const bool strip = h->strip && strip_lds <= 128 * 1024;
+    // two workgroups per strip (StripDuo) where the pairs fit the chip at one workgroup per CU: both halves of a pair must be
+    // resident to swap (bf16 strips of 32 examples: 256 workgroups at batch 4096)
+    const int nstrips = Ba / (16 * RT);
+    const bool duo = strip && h->duo && RT == 2 && 2 * nstrips <= h->n_cu;
+    if (duo && !h->duo_xch) {
+        h->duo_xch_wg = (size_t)2 * ((maxD / 64 + 1) / 2) * RT * 256;       // 8-byte words: [2 parities][own blocks][RT][256]
+        IHK(h, hipMalloc((void**)&h->duo_xch, (size_t)(h->ldT / (16 * RT)) * 2 * h->duo_xch_wg * 8));
+        IHK(h, hipMalloc((void**)&h->duo_flags, (size_t)(h->ldT / (16 * RT)) * 2 * sizeof(int)));
+        IHK(h, hipMemsetAsync(h->duo_flags, 0, (size_t)(h->ldT / (16 * RT)) * 2 * sizeof(int), h->st));
+    }
     if (strip) {
         if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -942,8 +1070,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        h->d[t], B};
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
-        sa.dbg = h->stamps; sa.rot = h->strip_rot;
-        hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
+        sa.dbg = h->stamps; sa.rot = h->strip_rot; sa.sel = getenv("IPNN_STAMP_SEL") ? atoi(getenv("IPNN_STAMP_SEL")) : -1;
+        sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg};
+        hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
     } else {
     IpProf ps(h, "fwd");
     for (int t = 1; t <= L; ++t) {       // l_t = a_{t-1} W_t ; a_t = drop(act(l_t))
@@ -971,7 +1100,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        first ? h->ref0 : nullptr};
         }
         sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
-        hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(Ba / (16 * RT)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
+        sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg};
+        hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
     } else {
     IpProf ps(h, "bwd");
     for (int t = L + 1; t >= 1; --t) {   // delta l_{t-1} from delta l_t ; then gW_t = a_{t-1}^T delta l_t
@@ -1093,6 +1223,8 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_STRIP_DUO")) h->duo = atoi(e);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
     if (const char* e = getenv("IPNN_MASK_SIDE")) h->mask_side = atoi(e);
@@ -1187,7 +1319,7 @@ int ipnn_destroy(ipnn_handle* h)
     for (float* p : h->Wv) if (p) hipFree(p);
     for (float* p : {h->tm, h->tv, h->tG, h->bmv}) if (p) hipFree(p);
     void* ptrs[] = {h->table16, h->b, h->emb, h->dz0, h->gxp, h->gb_part, h->loss_t, h->loss_dev, h->slab, h->ref0, h->err_flag, h->rec,
-                    h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1};
+                    h->part, h->owners, h->owner_cnt, h->skeys, h->cpow1, h->duo_xch, h->duo_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& kv : h->prof_ev) for (auto& p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->st2) { hipStreamSynchronize(h->st2); hipStreamDestroy(h->st2); }
@@ -1206,7 +1338,11 @@ int ipnn_sync(ipnn_handle* h)
     int flag = 0;
     IHK(h, hipMemcpyAsync(&flag, h->err_flag, 4, hipMemcpyDeviceToHost, h->st));
     IHK(h, hipStreamSynchronize(h->st));
-    if (flag) { IHK(h, hipMemsetAsync(h->err_flag, 0, 4, h->st)); IFAIL(h, FNN_ERR_RANGE, "feature id outside [0, n_rows)"); }
+    if (flag) {
+        IHK(h, hipMemsetAsync(h->err_flag, 0, 4, h->st));
+        if (flag & 2) IFAIL(h, FNN_ERR_HIP, "a strip workgroup gave up waiting for its partner (StripDuo swap): results of that step are invalid; IPNN_STRIP_DUO=0 selects one workgroup per strip");
+        IFAIL(h, FNN_ERR_RANGE, "feature id outside [0, n_rows)");
+    }
     return FNN_OK;
 }
 
@@ -1385,18 +1521,37 @@ int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms)
     IHK(h, hipStreamSynchronize(h->st));
     *avg_ms = 0.0;
     if (h->stamps && (!strcmp(which, "fwd") || !strcmp(which, "bwd"))) {      // IPNN_STAMPS=1: the last step's per-layer stamps
-        const int nwg = h->ldT / (h->bf16 ? 32 : 16), np = h->L + 3;
+        const bool duo = h->duo_xch != nullptr;                    // pairs: even workgroups run the whole stack, odd ones the wide products only
+        const int nwg = h->ldT / (h->bf16 ? 32 : 16) * (duo ? 2 : 1), np = h->L + 3;
         std::vector<long long> st((size_t)nwg * 16);
         IHK(h, hipMemcpy(st.data(), h->stamps + (strcmp(which, "bwd") ? 0 : (size_t)(h->ldT / 16) * 16), st.size() * 8, hipMemcpyDeviceToHost));
-        long long t0 = st[0], t1 = 0;
-        for (int w = 0; w < nwg; ++w) { t0 = std::min(t0, st[(size_t)w * 16]); t1 = std::max(t1, st[(size_t)w * 16 + np - 1]); }
-        fprintf(stderr, "[ipnn stamps %s] %d workgroups, first start -> last end %lld ticks; avg ticks per phase (load, then products):", which, nwg, t1 - t0);
-        for (int i = 1; i < np; ++i) {
-            double s2 = 0; for (int w = 0; w < nwg; ++w) s2 += (double)(st[(size_t)w * 16 + i] - st[(size_t)w * 16 + i - 1]);
-            fprintf(stderr, " %.0f", s2 / nwg);
+        for (int par = 0; par < (duo ? 2 : 1); ++par) {
+            long long t0 = st[(size_t)par * 16], t1 = 0; int cnt = 0;
+            for (int w = par; w < nwg; w += duo ? 2 : 1) {
+                t0 = std::min(t0, st[(size_t)w * 16]); ++cnt;
+                for (int i = 0; i < np; ++i) t1 = std::max(t1, st[(size_t)w * 16 + i]);
+            }
+            fprintf(stderr, "[ipnn stamps %s%s] %d workgroups, first start -> last stamp %lld ticks; avg ticks per phase (load, then products):", which,
+                    duo ? (par ? " odd" : " even") : "", cnt, t1 - t0);
+            for (int i = 1; i < np; ++i) {
+                double s2 = 0; int c2 = 0;
+                for (int w = par; w < nwg; w += duo ? 2 : 1)
+                    if (st[(size_t)w * 16 + i] > st[(size_t)w * 16 + i - 1]) { s2 += (double)(st[(size_t)w * 16 + i] - st[(size_t)w * 16 + i - 1]); ++c2; }
+                fprintf(stderr, " %.0f", c2 ? s2 / c2 : 0.0);
+            }
+            double sk = 0; for (int w = par; w < nwg; w += duo ? 2 : 1) sk += (double)(st[(size_t)w * 16] - t0);
+            fprintf(stderr, " | avg start skew %.0f", sk / cnt);
+            if (getenv("IPNN_STAMP_SEL") && !strcmp(which, "fwd")) {
+                double dd[3] = {0, 0, 0};
+                for (int w = par; w < nwg; w += duo ? 2 : 1) for (int i = 0; i < 3; ++i) dd[i] += (double)(st[(size_t)w * 16 + 11 + i] - st[(size_t)w * 16 + 10 + i]);
+                fprintf(stderr, " | product %s, wave 0, last block: aux+product %.0f, next+prefetch %.0f, epilogue %.0f", getenv("IPNN_STAMP_SEL"), dd[0] / cnt, dd[1] / cnt, dd[2] / cnt);
+            } else if (duo) {
+                double acc3[3] = {0, 0, 0};
+                for (int w = par; w < nwg; w += 2) for (int i = 0; i < 3; ++i) acc3[i] += (double)st[(size_t)w * 16 + 11 + i];
+                fprintf(stderr, " | swaps in all: drain+barrier %.0f, flag wait %.0f, pull %.0f", acc3[0] / cnt, acc3[1] / cnt, acc3[2] / cnt);
+            }
+            fprintf(stderr, "\n");
         }
-        double sk = 0; for (int w = 0; w < nwg; ++w) sk += (double)(st[(size_t)w * 16] - t0);
-        fprintf(stderr, " | avg start skew %.0f\n", sk / nwg);
     }
     auto it = h->prof_ev.find(which);
     if (it == h->prof_ev.end() || it->second.empty()) return FNN_OK;

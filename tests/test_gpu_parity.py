@@ -254,6 +254,9 @@ def test_two_features_of_one_field_both_rows_are_updated(built, B, prec):
             ft += pick
         rng.shuffle(ft)
         feats.append([int(v) for v in ft])
+    fbig = int(np.argmax(sizes))                            # a row that ONLY ever appears shadowed: first on line 0, its field's
+    rare = int(offs[fbig] + sizes[fbig] - 1)                # usual feature behind it
+    feats[0] = [rare] + feats[0] + [int(offs[fbig])]
     ident = {int(r): int(r) for r in range(rows.shape[0])}
     field_of = {int(r): int(fo[r]) for r in range(rows.shape[0])}
     y = (rng.uniform(size=B) < 0.3).astype(np.float32)

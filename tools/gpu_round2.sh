@@ -9,7 +9,7 @@ step() {   # name, seconds, command...
   echo "   rc=$rc"; tail -c 400 gpurun_out/$name.log | tail -3
   if [ $rc -ge 124 ]; then echo "killed: stopping"; exit $rc; fi
 }
-step gpu_tests 1000 python -m pytest tests -m gpu -q -x --timeout 600
+step gpu_tests 1000 python -m pytest tests -m gpu -q --timeout 600
 step bench_default 400 python bench.py
 step bench_dp_world1 200 env FNN_BENCH_FORCE_DP=1 python bench.py --no-extras --no-cpu-baseline
 step bench_rehearse2 300 env FNN_BENCH_REHEARSE=1 python bench.py --gpus 2 --no-extras --no-cpu-baseline --steps 100
