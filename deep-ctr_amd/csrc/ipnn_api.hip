@@ -362,8 +362,8 @@ constexpr int STRIP_MAXP = IPNN_MAX_HIDDEN + 1;                  // products of 
 // writes their outputs.  Workgroups b and b + 8 share an XCD, so the even XCDs only ever stream the even blocks' weights and
 // the odd XCDs the odd ones: half the weight footprint per L2.  Flags hold launch_epoch * 16 + (swap index + 1): they only
 // grow, so nothing is reset between launches; a poll gives up after DUO_SPIN_LIMIT tries and raises `err` (no hang on a bug).
-struct StripDuo { int on; unsigned long long* xch; int* flags; int epoch; int* err; size_t xch_wg; };
-constexpr int DUO_MIN_BLOCKS = 5;
+struct StripDuo { int on; unsigned long long* xch; int* flags; int epoch; int* err; size_t xch_wg; int min_blocks; };
+constexpr int DUO_MIN_BLOCKS = 5;                                // default of StripDuo::min_blocks (IPNN_DUO_MIN)
 constexpr int DUO_SPIN_LIMIT = 1 << 22;
 template <typename T> struct StripFwdArgs {
     const T* a0; int n;                                          // a0: F layout [Ba][Dp0]; n = L + 1
@@ -513,7 +513,7 @@ constexpr int STRIP_NW = 8;                                      // waves per st
 // A workgroup's LIST of a product's column blocks: all nblk of them, or -- a wide product of a pair (StripDuo) -- the
 // (nblk - h + 1) / 2 blocks j with j & 1 == h.
 struct StripItem { int p, blk; };
-__device__ __forceinline__ bool duo_split(const StripDuo& d, const int nblk) { return d.on && nblk >= DUO_MIN_BLOCKS; }
+__device__ __forceinline__ bool duo_split(const StripDuo& d, const int nblk) { return d.on && nblk >= d.min_blocks; }
 __device__ __forceinline__ int duo_count(const bool split, const int nblk, const int h) { return split ? (nblk - h + 1) >> 1 : nblk; }
 // Workgroups walk their list in rotated order (list entry i of a workgroup with rotation g is entry (i + g) mod cnt), so
 // that the workgroups of an XCD do not all stream the same weights -- the same L2 channels -- at the same moment.
@@ -940,7 +940,7 @@ struct ipnn_handle {
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
-    int duo = 1;                                     // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo)
+    int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
@@ -1071,7 +1071,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         sa.dbg = h->stamps; sa.rot = h->strip_rot; sa.sel = getenv("IPNN_STAMP_SEL") ? atoi(getenv("IPNN_STAMP_SEL")) : -1;
-        sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg};
+        sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
         hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
     } else {
     IpProf ps(h, "fwd");
@@ -1100,7 +1100,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        first ? h->ref0 : nullptr};
         }
         sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
-        sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg};
+        sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
         hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
     } else {
     IpProf ps(h, "bwd");
@@ -1224,6 +1224,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_GEMM_LDS")) h->gemm_lds = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP_DUO")) h->duo = atoi(e);
+    if (const char* e = getenv("IPNN_DUO_MIN")) h->duo_min = std::max(2, atoi(e));
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);

@@ -437,14 +437,22 @@ def test_demo_epochs_f32_logloss_auc_within_1e4(built, golden_dir):
 
 
 def test_demo_epochs_bf16_tracks_oracle(built, golden_dir):
-    """bf16 throughput mode: same run; logloss within 5e-3, AUC within 2e-2 (stated, not 1e-4)."""
+    """bf16 throughput mode: same run.  Observed on MI355X (profiles/r02b_bf16_demo_deltas.json): logloss 1.3e-4 (train) /
+    1.1e-4 (test), AUC 1.7e-4 (train) / 1.7e-3 (test; 500 examples: one swapped pair moves it by 1e-4) from the float64
+    oracle; asserted at about twice that -- not the 1e-4 of the f32 mode, and stated as such."""
     g = np.load(os.path.join(golden_dir, 'epoch.npz'))
     h = _run_demo_epochs(golden_dir, 'bf16')
-    print("bf16 demo deltas: logloss %.2e auc %.2e" % (np.abs(h[:, 3] - g['test_logloss']).max(),
-                                                      np.abs(h[:, 2] - g['test_auc']).max()))
-    assert np.abs(h[:, 1] - g['train_logloss']).max() <= 5e-3
-    assert np.abs(h[:, 3] - g['test_logloss']).max() <= 5e-3
-    assert np.abs(h[:, 2] - g['test_auc']).max() <= 2e-2
+    d = {'train_logloss': float(np.abs(h[:, 1] - g['train_logloss']).max()), 'test_logloss': float(np.abs(h[:, 3] - g['test_logloss']).max()),
+         'train_auc': float(np.abs(h[:, 0] - g['train_auc']).max()), 'test_auc': float(np.abs(h[:, 2] - g['test_auc']).max())}
+    print("bf16 demo deltas vs the float64 oracle: %r" % (d,))
+    try:                                                    # kept beside the profiles (DESIGN.md quotes them)
+        import json
+        os.makedirs(os.path.join(os.path.dirname(golden_dir), '..', 'gpurun_out'), exist_ok=True)
+        json.dump(d, open(os.path.join(os.path.dirname(golden_dir), '..', 'gpurun_out', 'bf16_demo_deltas.json'), 'w'))
+    except OSError:
+        pass
+    assert d['train_logloss'] <= 3e-4 and d['test_logloss'] <= 3e-4
+    assert d['train_auc'] <= 4e-4 and d['test_auc'] <= 4e-3
 
 
 def test_train_step_bf16_vs_oracle(built):

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 W=${1:-fnn}
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/pmc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/pmc_w.log 2>&1
 python3 tools/pmc_summarise.py gpurun_out/pmc_f gpurun_out/pmc_w > gpurun_out/pmc_traffic_$W.json
 cat gpurun_out/pmc_traffic_$W.json
