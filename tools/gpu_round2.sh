@@ -10,8 +10,9 @@ step() {   # name, seconds, command...
   if [ $rc -ge 124 ]; then echo "killed: stopping"; exit $rc; fi
 }
 step gpu_tests 1000 python -m pytest tests -m gpu -q --timeout 600
-step bench_default 400 python bench.py
+step bench_default 400 bash -c "time python bench.py"
 step bench_dp_world1 200 env FNN_BENCH_FORCE_DP=1 python bench.py --no-extras --no-cpu-baseline
 step bench_rehearse2 300 env FNN_BENCH_REHEARSE=1 python bench.py --gpus 2 --no-extras --no-cpu-baseline --steps 100
 step bench_rehearse2x 300 env FNN_BENCH_REHEARSE=1 python bench.py --gpus 2 --no-extras --no-cpu-baseline --steps 50 --dp-sparse exchange
 step step1_phases 200 bash tools/step1_phases.sh
+step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
