@@ -876,16 +876,34 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     const int lt = (int)(tile - u.off[t] / 4096), r0 = (lt / ntc) * 64, c0 = (lt % ntc) * 64;
     const int cq = (threadIdx.x & 15) * 4, sk = u.sk[t];
     T* wb = static_cast<T*>(u.wb[t]);
+    // the split-K slabs of the thread's 4 x 4 elements, summed in slab order: the loads of four slabs x four rows are issued
+    // together (a `for z: load, add` loop pays one memory round trip per slab and row: 21 -> 17 us for the whole launch)
+    float4 gs[4], ws[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ws[k] = *reinterpret_cast<const float4*>(u.W[t] + (size_t)(r0 + (threadIdx.x >> 4) + 16 * k) * Dout + c0 + cq);
+    }
+    for (int z0 = 0; z0 < sk; z0 += 4) {
+        float4 v[4][4];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t i = u.off[t] + (size_t)(r0 + (threadIdx.x >> 4) + 16 * k) * Dout + c0 + cq;
+                v[zz][k] = z0 + zz < sk ? *reinterpret_cast<const float4*>(u.slab + (size_t)(z0 + zz) * u.zstride + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gs[k].x += v[zz][k].x; gs[k].y += v[zz][k].y; gs[k].z += v[zz][k].z; gs[k].w += v[zz][k].w; }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + (threadIdx.x >> 4) + 16 * k, c = c0 + cq;
-        const size_t j = (size_t)r * Dout + c, i = u.off[t] + j;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < sk; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(u.slab + (size_t)z * u.zstride + i);
-            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
-        }
-        float4 w = *reinterpret_cast<const float4*>(u.W[t] + j);
+        const size_t j = (size_t)r * Dout + c;
+        const float4 g = gs[k];
+        float4 w = ws[k];
         if (u.adam) {
             float4 m = *reinterpret_cast<const float4*>(u.Wm[t] + j), v = *reinterpret_cast<const float4*>(u.Wv[t] + j);
             w.x = opt_step(u.adam, w.x, g.x, m.x, v.x, u.lr, u.beta1, u.beta2, u.eps);
@@ -1252,7 +1270,8 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         int sk = 1;
         // one launch per product wants ~256 workgroups each; the grouped launch runs all products side by side and is
         // served best by half of that (measured: 0.353 -> 0.345 ms/step; a quarter: 0.355)
-        const int want = h->group_wgrad ? 144 : 288;
+        int want = h->group_wgrad ? 144 : 288;
+        if (const char* e = getenv("IPNN_WGRAD_WANT")) want = std::max(16, atoi(e));       // tuning knob
         while (sk < h->splitk && tiles * sk * 2 <= want) sk *= 2;
         h->sk[t - 1] = sk;
     }
