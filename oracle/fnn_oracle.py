@@ -5,9 +5,13 @@ float64 NumPy restatement of the Theano FNN script of Atomu2014/deep-ctr
 `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
 module; the product path (`deep-ctr_amd/`) never does.
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures and
-cannot be executed in the build container (Python-2 syntax, Theano absent; see
-SURVEY.md section 8c).  This restatement is therefore pinned only by
+PINNED for A1-A3 (parse_fm_model, parse_line, feats_to_layer_one_array, gather): the
+reference's data_fm.DataFM is plain Python + NumPy and was run in the build container
+(tests/golden/make_golden_ref.py); tests/test_oracle_vs_reference.py holds these functions
+to its outputs, bit for bit.
+PARITY UNPINNED for the rest (A4-A6, A8, A10, A11's FNN form): the reference ships no tests,
+golden vectors or fixtures and its Theano scripts cannot be executed in the build
+container (Theano absent).  Those parts are pinned only by
   * the known-answer anchors of the legacy NumPy RNG it shares with the
     reference (`tests/test_oracle.py::test_rng_known_answers`),
   * finite-difference checks of every gradient it returns, and

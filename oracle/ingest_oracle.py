@@ -1,6 +1,8 @@
 """ORACLE (test infrastructure only -- the product never imports this): the reference's text
 parsers restated in Python 3, expression by expression, as the checker of the native ingestion
-(include/ctr_ingest.h).  parity unpinned: the reference ships no data files or parser tests.
+(include/ctr_ingest.h).  parse_fm_model, the FNN line rules and the yzx readers are PINNED against runs of the reference's own
+data_fm.DataFM / ipinyou.py (tests/golden/make_golden_ref.py -> tests/test_oracle_vs_reference.py); snn_active and pairs restate
+parsers that sit inside Theano scripts / are driven by them and stay parity unpinned (the reference ships no parser tests).
 
   parse_fm_model   python/FNN_wnzh.py:62-84  ==  python/data_fm.py:15-44
   fnn_examples     python/FNN_wnzh.py:224-253 (get_batch_data / get_fxy over the whole file)

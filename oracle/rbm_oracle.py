@@ -5,9 +5,10 @@ Atomu2014/deep-ctr: the online sparse CD-1 trainer (A7, `sparse_RBM` :294-402 +
 `sparse_CDTrainer.train` :413-508), the dense mini-batch CD-1 trainer (A7', `RBM` :10-124 +
 `CDTrainer.train` :168-291) and the layer-wise driver `get_rbm_weights` (:510-543).
 
-PARITY UNPINNED: the reference ships no fixtures and cannot run here (see oracle/fnn_oracle.py).
-Pinned by: shape/ordering quirks restated one by one below, the shared legacy NumPy RNG stream,
-and an independent vectorised re-derivation of one CD-1 step in tests/test_oracle.py.
+PINNED (A7, A7') against runs of the reference module itself: it is plain NumPy, so tests/golden/make_golden_ref.py executes
+it in the build container (through lib2to3; see that script) and tests/test_oracle_vs_reference.py holds get_rbm_weights --
+three epochs of both trainers, two configurations -- to the reference's own arrays within 1e-12.  (A8, the fine-tune step,
+lives in a Theano script and stays PARITY UNPINNED: see oracle/fnn_oracle.py.)
 """
 import numpy as np
 

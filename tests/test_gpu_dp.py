@@ -187,6 +187,33 @@ def test_two_virtual_ranks_local_sparse_prefetch_changes_nothing(built):
             assert np.array_equal(da[k], db[k]), k
 
 
+def test_two_virtual_ranks_layer_by_layer_path(built):
+    """Batches above 4096 examples take the layer-by-layer kernels; under native data parallelism their flat dense-gradient
+    bucket is what the library all-reduces (before its update kernel).  Two virtual ranks of 4,500 + 4,300 examples against
+    one engine stepping the 8,800; EXCHANGE has no layer-by-layer form and says so."""
+    G = 8800
+    rows, fo, ids, y, p, r1, r2 = make_problem(G, seed=81, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.05, lamfm=0.1, max_batch=16384)
+    full = make_engine(rows, fo, p, **kw)
+    ref_loss = full.train_step(ids, y, r1, r2)['loss']
+    ref_dense, ref_rows = full.get_dense(), full.get_table()
+    full.close()
+    cut = [slice(0, 4500), slice(4500, G)]
+    state, losses = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False)
+    assert abs(losses[0][0] + losses[1][0] - ref_loss) <= 3e-5 * abs(ref_loss)
+    for dense, _ in state:
+        _dense_close(dense, ref_dense, p, tol=5e-4)
+    t = [set(np.unique(ids[c])) for c in cut]
+    only0 = np.array(sorted(t[0] - t[1]))
+    change = np.abs(ref_rows - rows.astype(np.float32)).max()
+    assert np.abs(state[0][1][only0] - ref_rows[only0]).max() <= 3e-4 * change + 1e-7
+    eng = make_engine(rows, fo, p, **kw)
+    with pytest.raises(Exception) as e:
+        eng.dp_init_custom(0, 2, lambda v: None, lambda a, b: None, sparse='exchange')
+    assert 'three-launch' in str(e.value)
+    eng.close()
+
+
 def test_two_virtual_ranks_exchange_keeps_replicas_identical(built):
     """EXCHANGE mode: the step all-gathers (ids, gx') of the shards and every rank applies the global batch's row updates in
     global example order -> both tables equal the single-engine run on every row, bit for bit with each other."""

@@ -302,3 +302,16 @@ def test_baseline_early_stop_and_recalibration():
     assert bl.early_stop(5, [0.3, 0.2, 0.2, 0.3, 0.4], metric='rmse')
     assert not bl.early_stop(5, [0.9], metric='auc')             # too few smoothed points
     bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = 0, 1, 1, 2
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked(built):
+    """`python bench.py --gpus N` outside torchrun starts the ranks itself and must fail loudly when it cannot (round 1 ran
+    ONE rank and printed n_gpus: 1); under torchrun a WORLD_SIZE that disagrees with --gpus is an error too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FNN_BENCH_REHEARSE')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'GPU(s) visible' in (r.stderr + r.stdout)
+    env['WORLD_SIZE'] = '4'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in (r.stderr + r.stdout)
