@@ -102,3 +102,23 @@ def test_ip_l7_logits_fixture(built, golden_dir):
     pr = eng.predict(g['ids']).cpu().numpy()
     np.testing.assert_allclose(pr, 1.0 / (1.0 + np.exp(-g['logits'])), rtol=2e-4, atol=1e-6)
     eng.close()
+
+
+def test_gather_equals_the_reference_layer_one_arrays(built, golden_dir):
+    """A3 against the REFERENCE's own output (tests/golden/ref_run.npz: data_fm.DataFM.get_fxy_fm on 96 demo lines, run in the
+    build container by make_golden_ref.py): DataFM -> ids -> fnn_gather must reproduce its x, a float32 copy of the parsed rows."""
+    from deep_ctr_amd.data_fm import DataFM
+    ref = np.load(os.path.join(golden_dir, 'ref_run.npz'))
+    d = DataFM(os.path.join(golden_dir, 'demo', 'fm.model.txt'))
+    rows, fo, w0 = d.table()
+    eng = FNNEngine(len(d.name_field), d.k, 300, 100, max_batch=256, precision='f32')
+    eng.set_table(rows, fo, w0)
+    d.engine = eng
+    ids = np.stack([d.feats_to_ids([int(v) for v in r if v >= 0]) for r in ref['fm_line_feats']])
+    x = eng.gather(ids).cpu().numpy()
+    assert np.array_equal(x, ref['fm_line_x'].astype(np.float32))
+    # and through the reference-shaped loader call (linecache + fnn_gather)
+    f, xb, yb = d.get_batch_data(os.path.join(golden_dir, 'demo', 'train.fm.txt'), 1, 96)
+    assert np.array_equal(xb, ref['fm_line_x'].astype(np.float32)) and np.array_equal(yb, ref['fm_line_y'])
+    assert f == [[int(v) for v in r if v >= 0] for r in ref['fm_line_feats']]
+    eng.close()

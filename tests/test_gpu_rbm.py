@@ -47,6 +47,30 @@ def test_get_rbm_weights_matches_oracle(built, tmp_path):
         np.testing.assert_allclose(res[k], ref[k], rtol=2e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("tag", ['a', 'b'])
+def test_get_rbm_weights_against_the_reference_run(built, tmp_path, golden_dir, tag):
+    """The HIP pre-training (sparse online CD-1 + dense CD-1 layers, three epochs each) against what the REFERENCE's own
+    NumPy module returned for the same lines and seed (tests/golden/ref_run.npz, written by make_golden_ref.py in the build
+    container): f32 kernels vs the reference's float64, tolerances relative to the size of the parameter change."""
+    import os
+    ref = np.load(os.path.join(golden_dir, 'ref_run.npz'))
+    feats = ref['rbm_%s_feats' % tag]
+    arr = [int(v) for v in ref['rbm_%s_arr' % tag]]
+    path = tmp_path / 'train.fm.txt'
+    with open(path, 'w') as f:
+        for row in feats:
+            f.write('0 ' + ' '.join('%d:1' % v for v in row) + '\n')
+    dl_utils.seed_global(1234)
+    res = gbrbm.get_rbm_weights(str(path), arr, ncases=len(feats), batch_size=int(ref['rbm_%s_batch' % tag]))
+    x_dim, H0 = arr[0], arr[1]
+    p0 = np.random.RandomState(1234).uniform(-.1, .1, x_dim * H0 + x_dim + H0)
+    W0_init = p0[:x_dim * H0].reshape(x_dim, H0)
+    assert rel_change_err(res[0], ref['rbm_%s_res0' % tag], W0_init) < 2e-3
+    np.testing.assert_allclose(res[1], ref['rbm_%s_res1' % tag], rtol=0, atol=2e-3 * np.abs(ref['rbm_%s_res1' % tag] - p0[-H0:]).max() + 1e-7)
+    for k in range(2, len(res)):
+        np.testing.assert_allclose(res[k], ref['rbm_%s_res%d' % (tag, k)], rtol=3e-4, atol=3e-6)
+
+
 def test_dense_cd1_minibatches_and_bf16(built, tmp_path):
     """Two mini-batches per epoch (the short last batch ends the epoch, :286-287) in f32; bf16 runs."""
     path, lines_feats, x_dim = make_lines(tmp_path, n=250)
