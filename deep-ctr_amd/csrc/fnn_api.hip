@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -599,6 +600,8 @@ RcclApi g_rccl;
 
 int rccl_load(std::string& err)
 {
+    static std::mutex mu;                          // handles of several host threads may set up data parallelism at once
+    std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.lib) return FNN_OK;
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);

@@ -55,6 +55,7 @@ class DataParallelFNN(object):
         import torch
         dist, eng = self.dist, self.engine
         if dist.get_backend(self.group) == 'nccl':
+            torch.cuda.set_device(eng.device)               # the object broadcast below moves through the current device
             box = [eng.dp_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             eng.dp_init(self.rank, self.world, box[0], self.sparse)
