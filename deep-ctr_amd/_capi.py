@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfnn_hip.so")
+# FNN_HIP_LIB: another build of the same library (A/B measurements of a kernel change on one box); never a different backend
+LIB_PATH = os.environ.get("FNN_HIP_LIB") or os.path.join(_HERE, "libfnn_hip.so")
 
 FNN_OK = 0
 FNN_ERR_ARG, FNN_ERR_HIP, FNN_ERR_STATE, FNN_ERR_RANGE, FNN_ERR_NOMEM = -1, -2, -3, -4, -5

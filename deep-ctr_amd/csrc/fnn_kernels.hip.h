@@ -1357,7 +1357,10 @@ __device__ __forceinline__ void scat1_body(const ScatArgs& sa, const int blk)
     const int f = G / NQ, q = G % NQ, base = q * 16;
     const int4 mine = rec[(size_t)f * N2 + base + l];
     // both decay factors of an entry depend on its record only: its own weight c^(e-1-pos) and its
-    // segment's c^(e-s) -- fetched together with the gradients and the old rows, not after them
+    // segment's c^(e-s) -- fetched together with the gradients and the old rows, not after them.
+    // (The conditional loads below compile to a branch and a wait per entry.  Making all 34 of them unconditional puts them
+    // in flight together and was measured SLOWER inside the launch, 16.4 -> 18.2 us, A/B on one box with tools/gpu_ab.sh:
+    // the role shares its CUs' 64 B/clk texture path with the weight-gradient role, which the burst of dword loads starves.)
     const double wmine = (mine.x >= 0) ? cpow[mine.w - 1 - (base + l)] : 0.0;
     const double cmine = (mine.x >= 0) ? cpow[mine.w - mine.z] : 0.0;
     int row[16], sg[16], eg[16];
