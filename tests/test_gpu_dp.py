@@ -214,6 +214,43 @@ def test_two_virtual_ranks_layer_by_layer_path(built):
     eng.close()
 
 
+def test_two_virtual_ranks_bag_mode_native(built):
+    """The SNN fine-tune step (FNN_MODE_BAG) shards through the same native step: its slabs also carry the bag-bias gradient.
+    Dense tensors and bb0 of both ranks equal the single-engine step of the global batch; rows one rank alone touched equal
+    the full-batch result there."""
+    from test_gpu_parity import make_snn_engine, make_snn_problem
+    G = 900
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(G, seed=19, dup_col=4)
+    full = make_snn_engine(ww0, bb0, p)
+    ref_loss = full.train_step(ids, y, r1, r2)['loss']
+    ref_dense, ref_rows, ref_bb = full.get_dense(), full.get_table(), full.get_bag_bias()
+    full.close()
+    ranks = [make_snn_engine(ww0, bb0, p) for _ in range(2)]
+    vr = VirtualRanks(2)
+    for r, e in enumerate(ranks):
+        e.dp_init_custom(r, 2, vr.allreduce_for(r), None, sparse='local')
+    cut = [slice(0, 512), slice(512, G)]
+    losses = [None, None]
+
+    def rank_fn(r):
+        def go():
+            losses[r] = ranks[r].train_step(ids[cut[r]], y[cut[r]], r1, r2, b_size=G)['loss']
+        return go
+    vr.run([rank_fn(0), rank_fn(1)])
+    assert abs(losses[0] + losses[1] - ref_loss) <= 3e-5 * abs(ref_loss)
+    for e in ranks:
+        d = e.get_dense()
+        for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+            scale = np.abs(ref_dense[k] - np.asarray(p[k], np.float32)).max() + 1e-12
+            assert np.abs(d[k] - ref_dense[k]).max() <= 5e-4 * scale + 1e-7, k
+        assert np.abs(e.get_bag_bias() - ref_bb).max() <= 5e-4 * np.abs(ref_bb - bb0).max() + 1e-7
+    t = [set(np.unique(ids[c])) for c in cut]
+    only0 = np.array(sorted(t[0] - t[1]))
+    np.testing.assert_allclose(ranks[0].get_table()[only0], ref_rows[only0], rtol=1e-5, atol=2e-7)
+    for e in ranks:
+        e.close()
+
+
 def test_two_virtual_ranks_exchange_keeps_replicas_identical(built):
     """EXCHANGE mode: the step all-gathers (ids, gx') of the shards and every rank applies the global batch's row updates in
     global example order -> both tables equal the single-engine run on every row, bit for bit with each other."""
