@@ -355,7 +355,7 @@ constexpr int STRIP_MAXP = IPNN_MAX_HIDDEN + 1;                  // products of 
 // that is 128 of the chip's 256, each streaming every weight at the ~75 GB/s one CU draws from L2 -- the bound of these kernels.
 // The pair splits every WIDE product by output column blocks (block j belongs to workgroup j & 1), so each CU streams half the
 // weights, and swaps halves after it: a workgroup pushes its blocks of the new activation tile to `xch` with write-through
-// (sc1) 8-byte stores, drains them, raises its flag, polls its partner's and pulls the partner's blocks into its own LDS tile
+// (sc1) 16-byte stores, drains them, raises its flag, polls its partner's and pulls the partner's blocks into its own LDS tile
 // with sc1 loads (MI355X_MICROARCH.md, "Valid forms": every store and load of the handed-off bytes sc1, stores drained before
 // the flag, one lane polls, the others load behind a workgroup barrier).  Narrow products (fewer than DUO_MIN_BLOCKS column
 // blocks) are computed by BOTH workgroups -- their weights are a few hundred KB, a swap costs more -- and workgroup 0 alone
@@ -534,18 +534,23 @@ template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a
 
 // ---- the swap of a pair (StripDuo).  xch of workgroup (strip, h): [2 parities][own block r = j >> 1][RT][256] 8-byte words,
 // a block's RT x 2 KB in the order they have in the LDS tile (row tile m: k-steps 2 j and 2 j + 1 are adjacent there).
+typedef unsigned int duo_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte write-through stores / L1-bypassing loads of the swap buffer (raw buffer instructions with the sc1 cache policy: the
+// compiler keeps their wait counts, unlike inline assembly; 8-byte accesses run at 0.54-0.70 of the 16-byte rate)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t duo_rsrc(const StripDuo& d) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)d.xch, 0, (int)(d.xch_wg * 8 * (size_t)gridDim.x), 0x00020000);
+}
 template <typename T, int RT>
 __device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const int N, const int j, const int parity, const int lane)
 {   // by the wave that has just written block j of the tile `out` (LDS operations of one wave complete in order)
-    unsigned long long* dst = d.xch + (size_t)blockIdx.x * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + (size_t)(j >> 1) * (RT * 256);
+    const __amdgpu_buffer_rsrc_t rs = duo_rsrc(d);
+    const size_t dst = ((size_t)blockIdx.x * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + (size_t)(j >> 1) * (RT * 256)) * 8;     // bytes
 #pragma unroll
     for (int m = 0; m < RT; ++m) {
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(out + ft_off<T>(m * 16, j * 64, N));
-        unsigned long long v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = src[lane + 64 * q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + m * 256 + lane + 64 * q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+        const duo_u32x4* src = reinterpret_cast<const duo_u32x4*>(out + ft_off<T>(m * 16, j * 64, N));
+        const duo_u32x4 v0 = src[lane], v1 = src[lane + 64];
+        __builtin_amdgcn_raw_buffer_store_b128(v0, rs, (int)(dst + m * 2048 + lane * 16), 0, 16);                // aux 16 = sc1: write-through
+        __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (int)(dst + m * 2048 + (lane + 64) * 16), 0, 16);
     }
 }
 // every wave has drained its pushes -> flag -> the partner's flag -> the partner's blocks into `out`.  `pull` = false: this
@@ -573,16 +578,22 @@ __device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N,
     if (!pull) return;
     lds_barrier();
     if (dbg && threadIdx.x == 0) { ta = (long long)__builtin_amdgcn_s_memtime(); dbg[12] += ta - tb; }    // flag + the partner's
-    const int ph = h ^ 1, cntp = (nblk - ph + 1) >> 1, t = threadIdx.x, m = t >> 8, idx = t & 255;      // one 8-byte word per thread per block
-    const unsigned long long* src = d.xch + (size_t)(blockIdx.x ^ 1) * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + t;
-    for (int r0 = 0; r0 < cntp && t < RT * 256; r0 += 8) {
-        unsigned long long v[8];
+    // a block = RT x 2 KB = RT x 128 pieces of 16 bytes: threads 0..255 take the partner's blocks 0, 2, ..., threads 256..511 the odd ones
+    const int ph = h ^ 1, cntp = (nblk - ph + 1) >> 1, t = threadIdx.x, pc = t & 255, m = pc >> 7, idx = pc & 127;
+    const __amdgpu_buffer_rsrc_t rs = duo_rsrc(d);
+    const size_t src = ((size_t)(blockIdx.x ^ 1) * d.xch_wg + (size_t)parity * (d.xch_wg >> 1)) * 8 + (size_t)pc * 16;                 // bytes
+    for (int r0 = 0; r0 < cntp && m < RT; r0 += 8) {                 // four loads in flight per thread
+        duo_u32x4 v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            v[k] = r0 + k < cntp ? __hip_atomic_load(src + (size_t)(r0 + k) * (RT * 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + (t >> 8) + 2 * k;
+            if (r < cntp) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(src + (size_t)r * (RT * 2048)), 0, 16);           // sc1: from L2
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (r0 + k < cntp) reinterpret_cast<unsigned long long*>(out + ft_off<T>(m * 16, (2 * (r0 + k) + ph) * 64, N))[idx] = v[k];
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + (t >> 8) + 2 * k;
+            if (r < cntp) reinterpret_cast<duo_u32x4*>(out + ft_off<T>(m * 16, (2 * r + ph) * 64, N))[idx] = v[k];
+        }
     }
     if (dbg && threadIdx.x == 0) dbg[13] += (long long)__builtin_amdgcn_s_memtime() - ta;                  // pull (thread 0's share)
 }
