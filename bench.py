@@ -83,12 +83,15 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam', 'ftrl'],
                     help='--workload ipnn only: sgd (BASELINE configs[2]), or the reference family\'s adam / ftrl (dense table pass per step)')
-    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm'],
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm', 'e2e'],
                     help='fnn: BASELINE configs[1] (default; at N = 1 the other workloads ride along as extra_workloads).  '
                          'snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
                          'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
                          'gather: the standalone embedding gathers (A3: FM rows; A8: 200-wide bag rows) against the HBM roofline.  '
-                         'rbm: SNN pre-training of configs[4] -- the exact online sparse CD-1 pass and a dense CD-1 layer')
+                         'rbm: SNN pre-training of configs[4] -- the exact online sparse CD-1 pass and a dense CD-1 layer.  '
+                         'e2e: one epoch of `python FNN.py` end to end on synthetic TEXT files of the config shape: native parse of '
+                         'fm.model.txt and train.fm.txt, the training steps, the evaluation pass (row N1 of SURVEY 8f)')
+    ap.add_argument('--e2e-lines', type=int, default=1 << 20, help='--workload e2e: lines of the synthetic train.fm.txt')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline workload only (no precision_f32 / extra_workloads legs)')
     ap.add_argument('--dp-sparse', default='local', choices=['local', 'exchange'],
@@ -98,7 +101,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        if args.workload not in ('fnn', 'snn'):
+        if args.workload not in ('fnn', 'snn'):   # (e2e included: one process)
             raise SystemExit("--gpus %d: only the fnn / snn steps shard (replicas of %s are not launched)" % (args.gpus, args.workload))
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,6 +114,8 @@ def main():
         out = bench_gather(args)
     elif args.workload == 'rbm':
         out = bench_rbm(args)
+    elif args.workload == 'e2e':
+        out = bench_e2e(args)
     else:
         out = bench_fnn(args, args.precision, args.workload == 'snn')
         if out is not None and world == 1 and args.workload == 'fnn' and not args.no_extras:
@@ -431,6 +436,127 @@ def bench_fnn(args, precision, snn):
     del ids, y, m1, m2
     torch.cuda.empty_cache()
     return out
+
+
+def bench_e2e(args):
+    """One epoch of the FNN script end to end, from TEXT: what the reference does per epoch around its Theano call
+    (python/FNN_wnzh.py:224-253 linecache + get_fxy per line, :193-221 the evaluation pass re-parsing the whole file) against
+    the native path: fm.model.txt (937,670 features) and train.fm.txt parsed once by ctr_ingest.h, ids resident in HBM,
+    4096-example train steps with the next batch's grouping riding on each, fnn_eval on the device.  Files are synthetic
+    (written to a temporary directory, config shape, Zipf ids); the value is examples/s over parse + copy + train + eval."""
+    import shutil
+    import tempfile
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import ingest, synth
+    from deep_ctr_amd import dl_utils as ut
+    from deep_ctr_amd.data_fm import DataFM
+    from deep_ctr_amd.engine import FNNEngine
+    N, B = args.e2e_lines, args.batch
+    sizes = synth.field_sizes_ipinyou()
+    D = sum(sizes)
+    rows = synth.fm_table(D, K, 0.05, 1234)
+    fo = synth.field_of_row(sizes)
+    ids_np = synth.zipf_ids(N, sizes, 1.1, 4321)
+    y_np = (np.random.RandomState(5).uniform(size=N) < 0.02).astype(np.int32)
+    tmp = tempfile.mkdtemp(prefix='fnn_e2e_', dir=os.environ.get('TMPDIR', '/tmp'))
+    try:
+        t0 = time.perf_counter()
+        mpath, tpath = os.path.join(tmp, 'fm.model.txt'), os.path.join(tmp, 'train.fm.txt')
+        names = np.array(synth.FIELD_NAMES)[fo]
+        with open(mpath, 'w') as f:                               # feature id = row index here
+            f.write('%r %d %d\n' % (-3.0, D, K - 1))
+            for lo in range(0, D, 65536):
+                hi = min(D, lo + 65536)
+                body = np.char.mod('%.7g', rows[lo:hi])
+                f.write('\n'.join('%d %s %s:%d' % (i, ' '.join(body[i - lo]), names[i], i) for i in range(lo, hi)) + '\n')
+        np.savetxt(tpath, np.column_stack([y_np, ids_np]), fmt='%d ' + ' '.join(['%d:1'] * F))
+        t_gen = time.perf_counter() - t0
+        sz_m, sz_t = os.path.getsize(mpath), os.path.getsize(tpath)
+        threads = ingest.n_threads()
+        # ---- A1: the model
+        t0 = time.perf_counter()
+        data = DataFM(mpath)
+        t_model = time.perf_counter() - t0
+        # ---- A2: the examples
+        t0 = time.perf_counter()
+        ids, yy, sh = data.load_ids(tpath, want_shadowed=True)
+        t_parse = time.perf_counter() - t0
+        assert ids.shape == (N, F) and len(sh) == 0
+        # ---- engine + copies
+        t0 = time.perf_counter()
+        eng = FNNEngine(F, data.k, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0, lambda_fm=0.1)
+        r32, fo2, w0 = data.table()
+        eng.set_table(r32, fo2, w0)
+        ut.seed_global(1234)
+        eng.set_dense(ut.init_fnn_weights(XDIM, H1, H2, 'tanh'))
+        ids_d, y_d = eng.to_device(ids, yy)
+        yf_d = y_d.float()
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t0
+        m1 = torch.ones(H1, dtype=torch.uint8, device=ids_d.device)
+        m2 = torch.ones(H2, dtype=torch.uint8, device=ids_d.device)
+        nb = N // B
+        lib, h = eng.lib, eng.h
+        from deep_ctr_amd import _capi
+
+        def epoch():
+            with torch.cuda.stream(eng.stream):
+                for j in range(nb):
+                    if j + 1 < nb:
+                        lib.fnn_prefetch_ids(h, ids_d.data_ptr() + (j + 1) * B * F * 4, B)
+                    rc = lib.fnn_train_step(h, ids_d.data_ptr() + j * B * F * 4, yf_d.data_ptr() + j * B * 4, B, m1.data_ptr(), m2.data_ptr(), B,
+                                            None, None, _capi.FNN_MEM_DEVICE, None)
+                    if rc != 0:
+                        raise RuntimeError(lib.fnn_last_error(h).decode())
+            eng.sync()
+        epoch()                                                   # warm-up epoch (clocks, caches)
+        t0 = time.perf_counter()
+        epoch()
+        t_train = time.perf_counter() - t0
+        y_np2 = y_np.copy(); y_np2[:16] = 1                       # both classes present whatever the draw
+        y_d2 = torch.as_tensor(y_np2).to(ids_d.device)
+        eng.evaluate(ids_d[:B], y_d2[:B])
+        t0 = time.perf_counter()
+        ev = eng.evaluate(ids_d, y_d2)
+        t_eval = time.perf_counter() - t0
+        eng.close()
+        # ---- the reference's way, on a bounded sample: per-line Python parsing (oracle/ingest_oracle.fnn_examples = get_fxy per line)
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import ingest_oracle as ino
+            n_s = min(N, 50000)
+            spath = os.path.join(tmp, 'sample.fm.txt')
+            with open(tpath) as fi, open(spath, 'w') as fo_:
+                for _ in range(n_s):
+                    fo_.write(fi.readline())
+            ff = dict(zip(range(D), fo.tolist()))
+            fr = {i: i for i in range(D)}
+            t0 = time.perf_counter()
+            ino.fnn_examples(spath, ff, fr, F)
+            t_py = time.perf_counter() - t0
+            cpu = {'value': n_s / t_py, 'unit': 'lines/sec', 'cores': 1, 'kind': 'port',
+                   'sample': 'parse of %d lines by oracle.ingest_oracle.fnn_examples (the reference parses every line again for every epoch and every '
+                             'evaluation pass, python/FNN_wnzh.py:224-253,193-221); host has %d cores' % (n_s, os.cpu_count())}
+        t_all = t_parse + t_setup + t_train + t_eval
+        out = {
+            'metric': 'examples/sec', 'value': N / (t_parse + t_train + t_eval), 'unit': 'examples/sec', 'n_gpus': 1, 'steps': nb, 'warmup': nb,
+            'ms_per_step': t_train / nb * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'one epoch of the FNN script from text: parse train.fm.txt (%d lines, %.0f MB) + %d train steps of %d + '
+                                   'evaluation of all lines; model file 937670 features (%.0f MB) parsed once' % (N, sz_t / 1e6, nb, B, sz_m / 1e6)},
+            'phases_s': {'write synthetic files (not counted)': t_gen, 'parse fm.model.txt': t_model, 'parse train.fm.txt': t_parse,
+                         'engine set-up + copies to HBM (once per run, not counted)': t_setup, 'train epoch': t_train, 'evaluation pass': t_eval},
+            'ingest': {'threads': threads, 'model_MB_per_s': sz_m / 1e6 / t_model, 'model_rows_per_s': D / t_model,
+                       'examples_MB_per_s': sz_t / 1e6 / t_parse, 'examples_lines_per_s': N / t_parse},
+            'train_examples_per_s': nb * B / t_train, 'eval_examples_per_s': N / t_eval, 'eval': {k: ev[k] for k in ('auc', 'rmse', 'logloss')},
+            'roofline': None, 'cpu_baseline': cpu,
+            'note': 'value = lines / (parse + train epoch + evaluation): what one epoch of the script costs end to end once the files are parsed '
+                    'natively and the ids stay in HBM; the reference re-parses per epoch at the cpu_baseline rate',
+        }
+        del t_all
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def bench_rbm(args):
