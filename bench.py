@@ -129,7 +129,8 @@ def main():
                     r = fn(*a)
                     return {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline', 'kernel_ms',
                                                   'train_logloss_last_step', 'sparse_minibatch_4096', 'dense_cd1_200x300',
-                                                  'bag_gather_zipf', 'fm_gather') if k in r}
+                                                  'bag_gather_zipf', 'fm_gather', 'phases_s', 'ingest', 'train_examples_per_s',
+                                                  'eval_examples_per_s') if k in r}
                 except Exception as e:                    # an extra leg must not cost the headline line
                     return {'error': '%s: %s' % (type(e).__name__, e)}
             if args.precision == 'bf16':
@@ -144,6 +145,8 @@ def main():
             ex['fnn_ip_l7'] = leg(bench_ipnn, ip)
             ex['gather'] = leg(bench_gather, short)
             ex['snn_pretrain_rbm'] = leg(bench_rbm, short)
+            e2 = copy.copy(short); e2.e2e_lines = min(args.e2e_lines, 1 << 18)
+            ex['fnn_script_epoch_from_text'] = leg(bench_e2e, e2)
             out['extra_workloads'] = ex
             g = ex['gather']
             if 'error' not in g and out.get('roofline') is not None:
