@@ -52,8 +52,11 @@ struct Mapped {
 
 // end of the line that starts at `s`: [s, e) is the text, `next` the start of the following line
 inline void line_end(const char* p, size_t n, size_t s, size_t& e, size_t& next) {
-    size_t i = s;
-    while (i < n && p[i] != '\n' && p[i] != '\r') ++i;
+    if (s >= n) { e = next = n; return; }
+    const char* nl = static_cast<const char*>(memchr(p + s, '\n', n - s));
+    const size_t i_nl = nl ? (size_t)(nl - p) : n;
+    const char* cr = static_cast<const char*>(memchr(p + s, '\r', i_nl - s));      // a lone '\r' ends a line too
+    const size_t i = cr ? (size_t)(cr - p) : i_nl;
     e = i;
     if (i >= n) { next = n; return; }
     next = (p[i] == '\r' && i + 1 < n && p[i + 1] == '\n') ? i + 2 : i + 1;
@@ -134,17 +137,19 @@ inline bool py_float(const char* b, const char* e, double& out) {
 }
 
 struct Tok { const char* b; const char* e; };
+struct SepTable { bool t[256]; SepTable() { for (int c = 0; c < 256; ++c) t[c] = is_ws((char)c) || c == ':'; } };
 
 // `.replace(':', ' ').split()` (runs = true) or `.strip().replace(':', ' ').split(' ')` (runs = false)
 inline void tokenize(const char* p, size_t s, size_t e, bool runs, std::vector<Tok>& out) {
     out.clear();
     if (runs) {
+        static const SepTable sep;
         size_t i = s;
         while (i < e) {
-            while (i < e && (is_ws(p[i]) || p[i] == ':')) ++i;
+            while (i < e && sep.t[(unsigned char)p[i]]) ++i;
             if (i >= e) break;
             const size_t b = i;
-            while (i < e && !(is_ws(p[i]) || p[i] == ':')) ++i;
+            while (i < e && !sep.t[(unsigned char)p[i]]) ++i;
             out.push_back(Tok{p + b, p + i});
         }
     } else {
@@ -185,12 +190,59 @@ struct IdMap {
     }
 };
 
+// What the line parser asks per feature: id -> (row, field), one cache line per question and prefetchable, so that the 16
+// questions of a line overlap their misses (the table of a 937,670-row model is several MB: at one dependent miss after another
+// the parser spent most of its time waiting for them).  Dense id sets (max id < 4 n + 1024, the usual index files) get a direct
+// table, others an open-addressing table of 16-byte entries.  Built once the model is complete; read-only afterwards.
+struct Finder {
+    struct E { int64_t key; int32_t row; int32_t fld; };
+    std::vector<uint64_t> direct;                            // (row + 1) | field << 32; 0 = absent
+    std::vector<E> tab; uint64_t mask = 0;
+    void build(const std::vector<int64_t>& feat, const std::vector<int32_t>& field) {
+        direct.clear(); tab.clear();
+        const size_t n = feat.size();
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int64_t v : feat) { lo = std::min(lo, v); hi = std::max(hi, v); }
+        if (n && lo >= 0 && (uint64_t)hi < 4 * (uint64_t)n + 1024) {
+            direct.assign((size_t)hi + 1, 0);
+            for (size_t i = 0; i < n; ++i) direct[(size_t)feat[i]] = (uint64_t)(i + 1) | (uint64_t)(uint32_t)field[i] << 32;
+            return;
+        }
+        size_t c = 16; while (c < 2 * n + 2) c <<= 1;
+        tab.assign(c, E{INT64_MIN, -1, -1}); mask = c - 1;
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t j = IdMap::h(feat[i]) & mask;
+            while (tab[j].row >= 0) j = (j + 1) & mask;
+            tab[j] = E{feat[i], (int32_t)i, field[i]};
+        }
+    }
+    inline void prefetch(int64_t k) const {
+        if (!direct.empty()) { if ((uint64_t)k < direct.size()) __builtin_prefetch(&direct[(size_t)k]); }
+        else __builtin_prefetch(&tab[IdMap::h(k) & mask]);
+    }
+    inline bool find(int64_t k, int32_t& row, int32_t& fld) const {
+        if (!direct.empty()) {
+            if ((uint64_t)k >= direct.size()) return false;
+            const uint64_t v = direct[(size_t)k];
+            if (!v) return false;
+            row = (int32_t)(uint32_t)v - 1; fld = (int32_t)(v >> 32);
+            return true;
+        }
+        uint64_t j = IdMap::h(k) & mask;
+        while (tab[j].row >= 0 && tab[j].key != k) j = (j + 1) & mask;
+        if (tab[j].row < 0) return false;
+        row = tab[j].row; fld = tab[j].fld;
+        return true;
+    }
+};
+
 }  // namespace
 
 struct ctr_fm_model {
     int k = 0, n_fields = 0; double w0 = 0.0;
     std::vector<int64_t> feat; std::vector<int32_t> field; std::vector<double> rows;
-    IdMap map;
+    IdMap map;                                               // while the model is being put together (later lines overwrite)
+    Finder finder;                                           // what the line parser reads
 };
 
 extern "C" {
@@ -281,6 +333,7 @@ int ctr_fm_model_load(const char* path, const char* const* field_names, int n_fi
             }
         }
     }
+    m->finder.build(m->feat, m->field);
     *out = m;
     return CTR_OK;
 }
@@ -299,6 +352,7 @@ int ctr_fm_model_from_arrays(const int64_t* feat_ids, const int32_t* field_of_ro
         if (found) { delete m; return fail(CTR_ERR_ARG, "duplicate feature id"); }
         *sl = (int32_t)i;
     }
+    m->finder.build(m->feat, m->field);
     *out = m;
     return CTR_OK;
 }
@@ -359,6 +413,8 @@ int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int
     run_threads((int)rs.size(), [&](int t) {
         const Range& r = rs[t];
         std::vector<Tok> tok;
+        std::vector<int64_t> fid;
+        static const SepTable sep;
         std::vector<int64_t>& sh = shadows[t];
         size_t s = r.lo, e, nx; int64_t ln = r.line0 + 1, ex = r.ex0;
         for (; s < r.hi; s = nx, ++ln) {
@@ -368,23 +424,46 @@ int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int
             int32_t* vrow = vals_out ? vals_out + (size_t)ex * width : nullptr;
             for (int j = 0; j < width; ++j) row[j] = -1;
             if (vrow) for (int j = 0; j < width; ++j) vrow[j] = 0;
-            tokenize(f.p, s, e, mode == CTR_MODE_FNN, tok);
             int64_t y;
-            if (tok.empty() || !py_int(tok[0].b, tok[0].e, y) || y < INT32_MIN || y > INT32_MAX) { err.set(ln, CTR_ERR_PARSE, "label is not an int"); return; }
-            y_out[ex] = (int32_t)y;
             if (mode == CTR_MODE_FNN) {
-                for (size_t j = 1; j < tok.size(); j += 2) {
-                    int64_t feat;
-                    if (!py_int(tok[j].b, tok[j].e, feat)) { err.set(ln, CTR_ERR_PARSE, "feature id is not an int"); return; }
-                    const int32_t rr = m->map.get(feat);
-                    if (rr < 0) { err.set(ln, CTR_ERR_KEY, "feature " + std::to_string(feat) + " is not in the FM model (KeyError)"); return; }
-                    int32_t& slot = row[m->field[rr]];
+                // `.replace(':', ' ').split()` and int() of the label and of every second token after it, in ONE walk over the
+                // bytes: a token of 1..18 digits is read as it is scanned, anything else (sign, junk, 19+ digits) goes to py_int.
+                // Ids first (each prefetches its table entry), rows second: the misses of one line overlap.
+                fid.clear();
+                size_t i = s; int64_t nt = 0; bool have_y = false;
+                while (i < e) {
+                    while (i < e && sep.t[(unsigned char)f.p[i]]) ++i;
+                    if (i >= e) break;
+                    const size_t b = i; uint64_t v = 0; bool digits = true;
+                    for (; i < e && !sep.t[(unsigned char)f.p[i]]; ++i) {
+                        const unsigned d = (unsigned char)f.p[i] - (unsigned)'0';
+                        digits &= d <= 9; v = v * 10 + d;
+                    }
+                    if (nt == 0 || (nt & 1)) {
+                        int64_t val = (int64_t)v;
+                        if ((!digits || i - b > 18) && !py_int(f.p + b, f.p + i, val)) {
+                            err.set(ln, CTR_ERR_PARSE, nt == 0 ? "label is not an int" : "feature id is not an int"); return;
+                        }
+                        if (nt == 0) { y = val; have_y = true; }
+                        else { m->finder.prefetch(val); fid.push_back(val); }
+                    }
+                    ++nt;
+                }
+                if (!have_y || y < INT32_MIN || y > INT32_MAX) { err.set(ln, CTR_ERR_PARSE, "label is not an int"); return; }
+                y_out[ex] = (int32_t)y;
+                for (int64_t feat : fid) {
+                    int32_t rr, fld;
+                    if (!m->finder.find(feat, rr, fld)) { err.set(ln, CTR_ERR_KEY, "feature " + std::to_string(feat) + " is not in the FM model (KeyError)"); return; }
+                    int32_t& slot = row[fld];
                     // an earlier feature of the same field: the gather forgets it (the later one wins, data_fm.py:52-53), the
                     // update loop does not (python/FNN_wnzh.py:300-306 walks every feature of the line)
-                    if (slot >= 0) { sh.push_back(ex); sh.push_back(m->field[rr]); sh.push_back(slot); }
+                    if (slot >= 0) { sh.push_back(ex); sh.push_back(fld); sh.push_back(slot); }
                     slot = rr;
                 }
             } else {
+                tokenize(f.p, s, e, false, tok);
+                if (tok.empty() || !py_int(tok[0].b, tok[0].e, y) || y < INT32_MIN || y > INT32_MAX) { err.set(ln, CTR_ERR_PARSE, "label is not an int"); return; }
+                y_out[ex] = (int32_t)y;
                 if ((tok.size() & 1) == 0) { err.set(ln, CTR_ERR_PARSE, "id without a value (IndexError)"); return; }
                 int n = 0;
                 for (size_t j = 1; j + 1 < tok.size(); j += 2) {

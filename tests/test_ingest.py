@@ -153,6 +153,13 @@ def test_errors_keep_the_reference_exception_and_name_the_first_bad_line(built, 
     bad.write_bytes((body + "1 10:1 1.5:1\n").encode())
     with pytest.raises(ValueError, match=r'bad\.txt:3001'):
         ingest.parse_examples(str(bad), ingest.MODE_FNN, m, 16)
+    # every id of the line is read before any is looked up (the list comprehension of python/data_fm.py:72): junk after an
+    # unknown id is the ValueError, not the KeyError
+    bad.write_bytes(b"1 10:1\n1 99:1 zz:1\n")
+    with pytest.raises(ValueError, match=r'bad\.txt:2'):
+        ingest.parse_examples(str(bad), ingest.MODE_FNN, m, 16)
+    with pytest.raises(ValueError):
+        io.fnn_examples(str(bad), *_maps(str(mp))[3:])
     with pytest.raises(IOError):
         ingest.parse_examples(str(tmp_path / 'missing.txt'), ingest.MODE_FNN, m, 16)
     bm = tmp_path / 'badmodel.txt'
@@ -207,3 +214,35 @@ def test_fm_model_checkpoint_round_trip(built, golden_dir, tmp_path):
     e = DataFM(path)
     assert e.w_0 == d.w_0 and e.k == d.k and np.array_equal(e.feat_ids, d.feat_ids) and np.array_equal(e.field_of_row, d.field_of_row)
     assert np.array_equal(e.rows.astype(np.float32), rows)
+
+
+def test_sparse_and_dense_id_sets_and_odd_integer_spellings(built, tmp_path):
+    """The parser keeps a direct table for dense feature ids and an open-addressing one for sparse ids (ids up to 2^62 here):
+    both against the Python restatement, with the integer spellings int() accepts beside plain digits ('+7', '007', a
+    19-digit id, a negative label)."""
+    rng = np.random.RandomState(11)
+    n = 5000
+    for tag, feats in (('dense', rng.permutation(3 * n)[:n].astype(np.int64)),
+                       ('sparse', np.unique(rng.randint(1, 2 ** 62, size=n + 50, dtype=np.int64))[:n])):
+        feats = feats.copy(); rng.shuffle(feats)
+        feats[0] = 1234567890123456789 if tag == 'sparse' else feats[0]
+        fo = rng.randint(0, 16, size=n).astype(np.int32)
+        m = ingest.FMModel.from_arrays(feats, fo, 3, 16)
+        ff = {int(f): int(q) for f, q in zip(feats, fo)}
+        feat_row = {int(f): i for i, f in enumerate(feats)}
+        lines = []
+        for t in range(4000):
+            pick = feats[rng.randint(0, n, size=rng.randint(1, 17))]
+            lines.append('%d %s' % (t % 2, ' '.join('%d:1' % v for v in pick)))
+        lines.append('-1 +%d:1 00%d:+1' % (feats[1], feats[2]))
+        lines.append('+0 %d:1' % feats[0])
+        ep = tmp_path / ('%s.fm.txt' % tag)
+        ep.write_text('\n'.join(lines) + '\n')
+        rid, ry = io.fnn_examples(str(ep), ff, feat_row)
+        for threads in (1, 5):
+            ids, _, y = ingest.parse_examples(str(ep), ingest.MODE_FNN, m, 16, threads=threads)
+            assert np.array_equal(ids, rid) and np.array_equal(y, ry), tag
+        assert ry[-2] == -1 and rid[-1, fo[0]] == 0
+        ep.write_text('1 %d:1 %d:1\n' % (feats[3], int(feats.max()) + 1))
+        with pytest.raises(KeyError):
+            ingest.parse_examples(str(ep), ingest.MODE_FNN, m, 16)
