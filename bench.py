@@ -486,6 +486,14 @@ def bench_e2e(args):
         ids, yy, sh = data.load_ids(tpath, want_shadowed=True)
         t_parse = time.perf_counter() - t0
         assert ids.shape == (N, F) and len(sh) == 0
+        # ---- the binary id cache: written once (not counted), what a later run reads instead of parsing
+        cdir = os.path.join(tmp, 'cache')
+        data.load_ids(tpath, want_shadowed=True, cache_dir=cdir)
+        t0 = time.perf_counter()
+        ids_c, yy_c, _ = data.load_ids(tpath, want_shadowed=True, cache_dir=cdir)
+        t_cache = time.perf_counter() - t0
+        assert np.array_equal(ids_c, ids) and np.array_equal(yy_c, yy)
+        del ids_c, yy_c
         # ---- engine + copies
         t0 = time.perf_counter()
         eng = FNNEngine(F, data.k, H1, H2, max_batch=B, precision=args.precision, lr=0.001, lambda1=0.0, lambda_fm=0.1)
@@ -548,9 +556,11 @@ def bench_e2e(args):
             'config': {'workload': 'one epoch of the FNN script from text: parse train.fm.txt (%d lines, %.0f MB) + %d train steps of %d + '
                                    'evaluation of all lines; model file 937670 features (%.0f MB) parsed once' % (N, sz_t / 1e6, nb, B, sz_m / 1e6)},
             'phases_s': {'write synthetic files (not counted)': t_gen, 'parse fm.model.txt': t_model, 'parse train.fm.txt': t_parse,
+                         'read the binary id cache instead (later runs)': t_cache,
                          'engine set-up + copies to HBM (once per run, not counted)': t_setup, 'train epoch': t_train, 'evaluation pass': t_eval},
             'ingest': {'threads': threads, 'model_MB_per_s': sz_m / 1e6 / t_model, 'model_rows_per_s': D / t_model,
-                       'examples_MB_per_s': sz_t / 1e6 / t_parse, 'examples_lines_per_s': N / t_parse},
+                       'examples_MB_per_s': sz_t / 1e6 / t_parse, 'examples_lines_per_s': N / t_parse, 'cache_lines_per_s': N / t_cache},
+            'value_from_id_cache': N / (t_cache + t_train + t_eval),
             'train_examples_per_s': nb * B / t_train, 'eval_examples_per_s': N / t_eval, 'eval': {k: ev[k] for k in ('auc', 'rmse', 'logloss')},
             'roofline': None, 'cpu_baseline': cpu,
             'note': 'value = lines / (parse + train epoch + evaluation): what one epoch of the script costs end to end once the files are parsed '

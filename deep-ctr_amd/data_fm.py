@@ -7,6 +7,7 @@ Host logic only (text parsing, id mapping).  `get_batch_data` needs an attached 
 `x` (fnn_gather); the id fast path (`get_batch_ids`, `load_ids`) is what the training loop uses.
 """
 import linecache
+import os
 
 import numpy
 
@@ -33,6 +34,7 @@ class DataFM(object):
         self.xdim = 1 + len(self.name_field) * self.k
         self.rows, self.feat_ids, self.field_of_row = self.model.arrays()
         self._dicts = None
+        self._digest = None                                    # of the feature table, for the binary id cache
 
     def _build_dicts(self):
         if self._dicts is None:
@@ -117,16 +119,18 @@ class DataFM(object):
         ids = numpy.asarray(ids, dtype=numpy.int32).reshape(len(ys), len(self.name_field))
         return farray, ids, numpy.asarray(ys, dtype=numpy.int32)
 
-    def load_ids(self, file, want_shadowed=False):
+    def load_ids(self, file, want_shadowed=False, cache_dir=None):
         """Whole file -> (ids int32 [N,16], y int32 [N]); blank lines skipped.  One native pass
         (ctr_parse_examples, CTR_MODE_FNN) instead of get_fxy per line per epoch.  want_shadowed: also int32 [n, 3] =
-        (example, field, row) of the features a later feature of the same field shadows (see shadowed_of)."""
+        (example, field, row) of the features a later feature of the same field shadows (see shadowed_of).
+        cache_dir (or $FNN_IDS_CACHE): keep the parsed arrays as a binary file there, keyed by the text file's size / mtime and
+        this model's feature table (ingest.parse_examples_cached); a later run reads that instead of parsing."""
         from . import ingest
-        if want_shadowed:
-            ids, _, y, sh = ingest.parse_examples(file, ingest.MODE_FNN, self.model, len(self.name_field), want_shadowed=True)
-            return ids, y, sh
-        ids, _, y = ingest.parse_examples(file, ingest.MODE_FNN, self.model, len(self.name_field))
-        return ids, y
+        if self._digest is None and (cache_dir or os.environ.get('FNN_IDS_CACHE')):
+            self._digest = ingest.model_digest(self.model)
+        res = ingest.parse_examples_cached(file, ingest.MODE_FNN, self.model, len(self.name_field), want_shadowed=want_shadowed,
+                                           cache_dir=cache_dir, digest=self._digest)
+        return (res[0], res[2], res[3]) if want_shadowed else (res[0], res[2])
 
     def shadowed_of(self, feats_per_example):
         """(example, field, row) int32 [n, 3] of every feature of the given lines (lists of feature ids, as get_batch_ids

@@ -116,6 +116,102 @@ def parse_examples(path, mode, model=None, width=16, threads=None, want_shadowed
     return ids, vals, y
 
 
+# ---------------------------------------------------------------------------------------------- binary id cache
+# "int32 [N,16] + uint8 y[N] binary cache".  The parsed form of an example file -- row indices of
+# the FM model, labels, shadowed features -- written once beside a key that names what it was parsed from: the text file's
+# size and mtime, the parse mode and width, and a digest of the model's (feature id, field) table in row order (the ids ARE row
+# indices of that table).  A cache whose key differs is ignored and rewritten.  Opt-in: `cache_dir=` or the environment
+# variable FNN_IDS_CACHE (a directory); the reference writes no such files, so nothing is written by default.
+_CACHE_MAGIC = b'CTRIDS02'
+
+
+def model_digest(model):
+    import hashlib
+    if model is None:
+        return '-'
+    _, feat, fo = model.arrays(want_rows=False)
+    h = hashlib.blake2b(digest_size=16)
+    h.update(np.ascontiguousarray(feat, np.int64).tobytes())
+    h.update(np.ascontiguousarray(fo, np.int32).tobytes())
+    return h.hexdigest()
+
+
+def _cache_key(path, mode, model, width, digest=None):
+    st = os.stat(path)
+    return 'size=%d mtime_ns=%d mode=%d width=%d model=%s' % (st.st_size, st.st_mtime_ns, mode, width, digest or model_digest(model))
+
+
+def cache_file(path, cache_dir, mode=MODE_FNN):
+    import hashlib
+    tag = hashlib.blake2b(os.path.abspath(path).encode(), digest_size=6).hexdigest()
+    return os.path.join(cache_dir, '%s.%s.m%d.ids' % (os.path.basename(path), tag, mode))
+
+
+def write_ids_cache(cpath, key, ids, vals, y, shadowed):
+    """header: magic, key length + key, n, width, n_shadowed, flags; then ids int32 [n,width], (vals int32 [n,width]), y uint8 [n]
+    when every label fits a byte else int32 [n], shadowed int32 [ns,3].  Written to a temporary name and renamed."""
+    n, width = ids.shape
+    y = np.ascontiguousarray(y, np.int32)
+    y8 = bool(n == 0 or (y.min() >= 0 and y.max() <= 255))
+    sh = np.zeros((0, 3), np.int32) if shadowed is None else np.ascontiguousarray(shadowed, np.int32)
+    kb = key.encode()
+    tmp = '%s.tmp%d' % (cpath, os.getpid())
+    with open(tmp, 'wb') as f:
+        f.write(_CACHE_MAGIC)
+        np.array([len(kb), n, width, len(sh), (1 if y8 else 0) | (2 if vals is not None else 0) | (4 if shadowed is not None else 0)], np.int64).tofile(f)
+        f.write(kb)
+        f.write(b'\0' * (-f.tell() % 64))
+        np.ascontiguousarray(ids, np.int32).tofile(f)
+        if vals is not None:
+            np.ascontiguousarray(vals, np.int32).tofile(f)
+        (y.astype(np.uint8) if y8 else y).tofile(f)
+        f.write(b'\0' * (-f.tell() % 4))
+        sh.tofile(f)
+    os.replace(tmp, cpath)
+
+
+def read_ids_cache(cpath, key, want_shadowed=False):
+    """(ids, vals, y[, shadowed]) or None when the file is missing, was written for another key, lacks the shadow list that is
+    asked for, or is cut short."""
+    try:
+        with open(cpath, 'rb') as f:
+            if f.read(8) != _CACHE_MAGIC:
+                return None
+            hdr = np.fromfile(f, np.int64, 5)
+            if len(hdr) != 5:
+                return None
+            klen, n, width, ns, flags = (int(v) for v in hdr)
+            if klen != len(key.encode()) or f.read(klen).decode(errors='replace') != key or (want_shadowed and not flags & 4):
+                return None
+            f.seek(-f.tell() % 64, 1)
+            ids = np.fromfile(f, np.int32, n * width)
+            vals = np.fromfile(f, np.int32, n * width) if flags & 2 else None
+            y = np.fromfile(f, np.uint8 if flags & 1 else np.int32, n)
+            f.seek(-f.tell() % 4, 1)
+            sh = np.fromfile(f, np.int32, ns * 3)
+            if len(ids) != n * width or len(y) != n or len(sh) != ns * 3 or (vals is not None and len(vals) != n * width):
+                return None
+    except (IOError, OSError):
+        return None
+    out = (ids.reshape(n, width), None if vals is None else vals.reshape(n, width), y.astype(np.int32))
+    return out + (sh.reshape(ns, 3),) if want_shadowed else out
+
+
+def parse_examples_cached(path, mode, model=None, width=16, threads=None, want_shadowed=False, cache_dir=None, digest=None):
+    """parse_examples behind the binary cache; cache_dir None -> $FNN_IDS_CACHE -> no cache at all."""
+    cache_dir = cache_dir or os.environ.get('FNN_IDS_CACHE')
+    if not cache_dir:
+        return parse_examples(path, mode, model, width, threads, want_shadowed)
+    os.makedirs(cache_dir, exist_ok=True)
+    key, cpath = _cache_key(path, mode, model, width, digest), cache_file(path, cache_dir, mode)
+    got = read_ids_cache(cpath, key, want_shadowed)
+    if got is not None:
+        return got
+    res = parse_examples(path, mode, model, width, threads, want_shadowed=(mode == MODE_FNN))    # the cache always carries the shadow list
+    write_ids_cache(cpath, key, res[0], res[1], res[2], res[3] if mode == MODE_FNN else None)
+    return (res if want_shadowed else res[:3]) if mode == MODE_FNN else res
+
+
 def _capi_err_cap():
     return -5          # CTR_ERR_CAP (include/ctr_ingest.h)
 

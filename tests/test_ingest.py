@@ -246,3 +246,51 @@ def test_sparse_and_dense_id_sets_and_odd_integer_spellings(built, tmp_path):
         ep.write_text('1 %d:1 %d:1\n' % (feats[3], int(feats.max()) + 1))
         with pytest.raises(KeyError):
             ingest.parse_examples(str(ep), ingest.MODE_FNN, m, 16)
+
+
+def test_binary_id_cache_round_trip_and_invalidation(built, golden_dir, tmp_path, monkeypatch):
+    """the parsed ids / labels / shadow list as a binary cache.  A second load reads the cache (the text file
+    can even be unreadable garbage of the same size and mtime); touching the text, or loading with another model, re-parses."""
+    import shutil
+    demo = os.path.join(golden_dir, 'demo')
+    src = tmp_path / 'train.fm.txt'
+    shutil.copy(os.path.join(demo, 'train.fm.txt'), src)
+    cdir = tmp_path / 'cache'
+    d = DataFM(os.path.join(demo, 'fm.model.txt'))
+    ids0, y0, sh0 = d.load_ids(str(src), want_shadowed=True)
+    ids1, y1, sh1 = d.load_ids(str(src), want_shadowed=True, cache_dir=str(cdir))       # parses and writes
+    files = os.listdir(cdir)
+    assert len(files) == 1 and files[0].startswith('train.fm.txt.')
+    assert np.array_equal(ids0, ids1) and np.array_equal(y0, y1) and np.array_equal(sh0, sh1)
+    # same size + mtime, different bytes: only a cache hit can return the old arrays
+    st = os.stat(src)
+    src.write_bytes(b'x' * st.st_size)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    ids2, y2 = d.load_ids(str(src), cache_dir=str(cdir))
+    assert np.array_equal(ids0, ids2) and np.array_equal(y0, y2) and ids2.dtype == np.int32 and y2.dtype == np.int32
+    monkeypatch.setenv('FNN_IDS_CACHE', str(cdir))                                       # the environment form
+    ids3, y3, sh3 = d.load_ids(str(src), want_shadowed=True)
+    assert np.array_equal(ids0, ids3) and np.array_equal(sh0, sh3)
+    monkeypatch.delenv('FNN_IDS_CACHE')
+    # a changed text file (new mtime) is parsed again: the garbage now raises
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 10 ** 9))
+    with pytest.raises(ValueError):
+        d.load_ids(str(src), cache_dir=str(cdir))
+    # another model (rows in another order): the key differs, the cache is not used
+    shutil.copy(os.path.join(demo, 'train.fm.txt'), src)
+    ids4, y4 = d.load_ids(str(src), cache_dir=str(cdir))
+    rows, feat, fo = d.model.arrays()
+    m2 = ingest.FMModel.from_arrays(feat[::-1].copy(), fo[::-1].copy(), d.k, 16)
+    r = ingest.parse_examples_cached(str(src), ingest.MODE_FNN, m2, 16, cache_dir=str(cdir))
+    assert np.array_equal(r[0][r[0] >= 0], len(feat) - 1 - ids4[ids4 >= 0]) and np.array_equal(ids4, ids0)
+    # a truncated cache file is ignored
+    cp = os.path.join(cdir, os.listdir(cdir)[0])
+    open(cp, 'r+b').truncate(os.path.getsize(cp) // 2)
+    ids5, y5 = d.load_ids(str(src), cache_dir=str(cdir))
+    assert np.array_equal(ids5, ids0)
+    # labels outside a byte are kept as int32; the pair mode carries its values
+    sp = tmp_path / 'snn.txt'
+    sp.write_bytes(b"300 5:1 6:0 7:1\n-2 8:2\n")
+    for _ in range(2):
+        pi, pv, py_ = ingest.parse_examples_cached(str(sp), ingest.MODE_PAIRS, None, 4, cache_dir=str(cdir))
+        assert py_.tolist() == [300, -2] and pv[0].tolist() == [1, 0, 1, 0] and pi[1].tolist() == [8, -1, -1, -1]
