@@ -94,6 +94,9 @@ def main():
     ap.add_argument('--e2e-lines', type=int, default=1 << 20, help='--workload e2e: lines of the synthetic train.fm.txt')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline workload only (no precision_f32 / extra_workloads legs)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="weak: --batch examples per GPU (the contract's default); strong: --batch is the GLOBAL batch, split over the ranks "
+                         "(SURVEY 8d config 4, '4096 split 8-way')")
     ap.add_argument('--dp-sparse', default='local', choices=['local', 'exchange'],
                     help='N > 1: local = every rank applies its own shard\'s row updates (north_star); exchange = the exact mode')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -223,6 +226,10 @@ def bench_fnn(args, precision, snn):
         local_rank = 0
     dev = torch.device('cuda', local_rank)
     B = args.batch
+    if args.scaling == 'strong':
+        if args.batch % (16 * world):
+            raise SystemExit("--scaling strong: --batch %d does not split into %d shards of whole 16-example strips" % (args.batch, world))
+        B = args.batch // world
     NB = 32                                               # distinct resident batches, cycled
 
     # ---- synthetic workload, seeded (table identical on every rank; ids differ per rank)
@@ -418,12 +425,12 @@ def bench_fnn(args, precision, snn):
         out = {
             'metric': 'examples/sec', 'value': value, 'unit': 'examples/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': precision, 'data': 'synthetic',
             'config': {'workload': ('SNN fine-tune step: 16 fields, 937670 x 200 bag table, hidden 300/100 tanh, batch '
-                                    '4096 per GPU, Zipf(1.1) ids' if snn else
+                                    '%d per GPU, Zipf(1.1) ids' % B if snn else
                                     'FNN L3 train step: 16 fields, 937670 one-hot dims, k=10, hidden 300/100 '
-                                    'tanh, batch 4096 per GPU, Zipf(1.1) ids'),
+                                    'tanh, batch %d per GPU, Zipf(1.1) ids' % B),
                        'per_gpu_batch': B, 'global_batch': gB,
                        'parallelism': 'dp%d' % world if world > 1 else 'single'},
             'train_logloss_last_step': last_loss,
