@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 F, K, H1, H2 = 16, 11, 300, 100
 XDIM = 1 + F * K
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+# bf16x3: three v_mfma_f32_16x16x16_bf16 per product; that instruction's nominal rate is half the 16x16x32 form's
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 6}
 
 # ALGORITHMIC bytes / flops per example of each kernel
 ALGO = {
@@ -80,7 +81,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='examples per GPU per step')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32', 'bf16x3'],
+                    help='bf16x3 (operands as bf16 pairs, three MFMAs per product): the fnn / snn / e2e workloads')
     ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam', 'ftrl'],
                     help='--workload ipnn only: sgd (BASELINE configs[2]), or the reference family\'s adam / ftrl (dense table pass per step)')
     ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm', 'e2e'],
@@ -111,6 +113,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torchrun: bench.py starts the "
                          "ranks itself)" % (args.gpus, world, args.gpus))
+    if args.precision == 'bf16x3' and args.workload in ('ipnn', 'rbm', 'gather'):
+        raise SystemExit("--precision bf16x3 is the FNN / SNN engine's (workloads fnn, snn, e2e)")
     if args.workload == 'ipnn':
         out = bench_ipnn(args)
     elif args.workload == 'gather':
@@ -141,6 +145,8 @@ def main():
                 # on the same workload beside the bf16 headline
                 short.no_cpu_baseline = True
                 out['precision_f32'] = leg(bench_fnn, short, 'f32', False)
+                # ... and the bf16-pair mode, which meets it too (tests/test_gpu_bf16x3.py) at 4.4x the f32 MFMA rate
+                out['precision_bf16x3'] = leg(bench_fnn, short, 'bf16x3', False)
                 short.no_cpu_baseline = args.no_cpu_baseline
             ex = {}
             ex['snn_finetune'] = leg(bench_fnn, short, args.precision, True)
@@ -367,7 +373,8 @@ def bench_fnn(args, precision, snn):
             ach = per_ex * B / t_s / 1e12
             peak, unit = MFMA_PEAK_TFLOPS[precision], 'TFLOP/s'
         roofline = {'kernel': dom, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                    'frac': ach / peak, 'traffic': pmc_traffic(dom, snn), 'avg_launch_ms': cand[dom],
+                    'frac': ach / peak, 'traffic': pmc_traffic(dom, snn) if precision == 'bf16' else None,       # the committed PMC passes are of the bf16 mode
+                    'avg_launch_ms': cand[dom],
                     # an event-bracketed slot = kernel + the event mechanism (a back-to-back pair alone: 'event_pair_ms');
                     # the kernel-only average of the committed rocprofv3 summary of this command is quoted beside it
                     'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if (snn or precision != 'bf16') else rocprof_avg_ms(dom),

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("FNN_HIP_LIB") or os.path.join(_HERE, "libfnn_hip.so")
 
 FNN_OK = 0
 FNN_ERR_ARG, FNN_ERR_HIP, FNN_ERR_STATE, FNN_ERR_RANGE, FNN_ERR_NOMEM = -1, -2, -3, -4, -5
-FNN_PREC_F32, FNN_PREC_BF16 = 0, 1
+FNN_PREC_F32, FNN_PREC_BF16, FNN_PREC_BF16X3 = 0, 1, 2
+PRECISIONS = {'f32': FNN_PREC_F32, 'bf16': FNN_PREC_BF16, 'bf16x3': FNN_PREC_BF16X3}
 FNN_ACT_TANH, FNN_ACT_SIGMOID, FNN_ACT_LINEAR = 0, 1, 2
 FNN_MEM_HOST, FNN_MEM_DEVICE = 0, 1
 FNN_MODE_FM, FNN_MODE_BAG = 0, 1

@@ -45,7 +45,8 @@ struct fnn_handle {
     size_t n1 = 0, n2 = 0, nw12 = 0, nw = 0;
     int splitk = 4;             // split-K of the weight-gradient products (measured: 4 -> 40.8 us per step, 8 -> 42.9, 2 -> 51.1)
     int scat2_wgs = 256;        // workgroups walking the multi-chunk segments in launch 3
-    bool bf16 = false;
+    bool bf16 = false;          // FNN_PREC_BF16: 2-byte elements
+    bool split = false;         // FNN_PREC_BF16X3: 4-byte elements (bs16_t), the f32 mode's layouts
     bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
     float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
     bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
@@ -134,6 +135,9 @@ template <typename T> int alloc_dev(fnn_handle* h, T** p, size_t n, bool zero = 
 }
 
 size_t tsize(const fnn_handle* h) { return h->bf16 ? 2 : 4; }
+// the element type of the handle's precision: FN<T> ARGS
+#define BY_PREC(h, FN, ARGS) do { if ((h)->bf16) FN<bf16_t> ARGS; else if ((h)->split) FN<bs16_t> ARGS; else FN<float> ARGS; } while (0)
+#define BY_PREC_RC(h, FN, ARGS) ((h)->bf16 ? FN<bf16_t> ARGS : ((h)->split ? FN<bs16_t> ARGS : FN<float> ARGS))
 
 int check_async(fnn_handle* h) {
     int flag = 0;
@@ -684,7 +688,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     if (cfg->mode == FNN_MODE_FM && (cfg->k < 1 || cfg->k > 15)) { g_create_err = "k = rank+1 must be in [1, 15] (two pad slots of the 16-float row carry w_0 and the bias)"; return FNN_ERR_ARG; }
     if (cfg->hidden1 < 1 || cfg->hidden1 > 4095 || cfg->hidden2 < 1 || cfg->hidden2 > 255) { g_create_err = "hidden1 must be in [1, 4095], hidden2 in [1, 255]"; return FNN_ERR_ARG; }
     if (cfg->max_batch < 1 || cfg->max_batch > 16384) { g_create_err = "max_batch must be in [1, 16384] (per-field LDS sort)"; return FNN_ERR_ARG; }
-    if (cfg->precision != FNN_PREC_F32 && cfg->precision != FNN_PREC_BF16) { g_create_err = "bad precision"; return FNN_ERR_ARG; }
+    if (cfg->precision != FNN_PREC_F32 && cfg->precision != FNN_PREC_BF16 && cfg->precision != FNN_PREC_BF16X3) { g_create_err = "bad precision"; return FNN_ERR_ARG; }
     if (cfg->act < 0 || cfg->act > 2) { g_create_err = "bad act"; return FNN_ERR_ARG; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -710,7 +714,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->N2max = SORT_N; while (h->N2max < h->Bmax) h->N2max <<= 1;    // the three-launch path groups SORT_N slots per field whatever max_batch is
     h->n1 = (size_t)h->K1p * h->H1p; h->n2 = (size_t)h->H1p * h->H2p;
     h->nw12 = h->n1 + h->n2; h->nw = h->nw12 + h->H2p;
-    h->bf16 = cfg->precision == FNN_PREC_BF16;
+    h->bf16 = cfg->precision == FNN_PREC_BF16; h->split = cfg->precision == FNN_PREC_BF16X3;
     if (const char* ev = getenv("FNN_NO_FUSE")) h->fused = !(ev[0] == '1');
     if (const char* ev = getenv("FNN_ROLE_OFF")) h->role_off = atoi(ev);
     if (const char* ev = getenv("FNN_SPLITK")) { const int v = atoi(ev); if (v == 2 || v == 4 || v == 8 || v == 16) h->splitk = v; }   // tuning knob
@@ -752,6 +756,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
         std::vector<unsigned char> ones(Ba * 64 * ts, 0);
         for (size_t t = 0; t < Ba; ++t) {
             if (h->bf16) { const unsigned short one = 0x3F80; memcpy(&ones[ft_off<bf16_t>(0, (int)t, (int)Ba) * 2], &one, 2); }
+            else if (h->split) { const bs16_t one(1.0f); memcpy(&ones[ft_off<bs16_t>(0, (int)t, (int)Ba) * 4], &one, 4); }
             else { const float one = 1.0f; memcpy(&ones[ft_off<float>(0, (int)t, (int)Ba) * 4], &one, 4); }
         }
         HK(hipMemcpy(h->onesT, ones.data(), ones.size(), hipMemcpyHostToDevice));
@@ -939,7 +944,7 @@ int fnn_set_dense(fnn_handle* h, int layer, const float* W, const float* b, int 
         memcpy(p.data(), hw.data(), H2 * 4); p[H2] = hb[0];
         HIPCHK(h, hipMemcpy(h->master + h->nw12, p.data(), (size_t)H2p * 4, hipMemcpyHostToDevice));
     }
-    if (h->bf16) launch_update<bf16_t>(h, nullptr, 0.f); else launch_update<float>(h, nullptr, 0.f);
+    BY_PREC(h, launch_update, (h, nullptr, 0.f));
     HIPCHK(h, hipStreamSynchronize(h->st));
     h->dense_set[layer - 1] = true;
     return FNN_OK;
@@ -1065,11 +1070,9 @@ static int step_impl(fnn_handle* h, const int32_t* ids, const float* y, int B, c
     h->step_native_dp = inline_update && h->dp;
     h->step_bsize = b_size;
     if (fast)
-        rc = h->bf16 ? run_step_fast<bf16_t>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update)
-                     : run_step_fast<float>(h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update);
+        rc = BY_PREC_RC(h, run_step_fast, (h, ids_d, y_d, B, m1, m2, p_d, gx_d, inline_update));
     else
-        rc = h->bf16 ? run_step<bf16_t>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d)
-                     : run_step<float>(h, ids_d, y_d, B, m1, m2, true, p_d, gx_d);
+        rc = BY_PREC_RC(h, run_step, (h, ids_d, y_d, B, m1, m2, true, p_d, gx_d));
     h->n_shadow = 0;                                            // consumed (also by a failing step)
     if (rc != FNN_OK) return rc;
     if (memkind == FNN_MEM_HOST) {
@@ -1124,7 +1127,7 @@ int fnn_step_scatter(fnn_handle* h)
     if (!h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_step_scatter without fnn_step_begin");
     HIPCHK(h, hipSetDevice(h->dev));
     if (h->scatter_pending) {
-        if (h->bf16) launch_steps23<bf16_t>(h, false, true, false); else launch_steps23<float>(h, false, true, false);
+        BY_PREC(h, launch_steps23, (h, false, true, false));
         HIPCHK(h, hipGetLastError());
     }
     return FNN_OK;
@@ -1228,7 +1231,7 @@ int fnn_step_end(fnn_handle* h, float* loss_sum_out)
             if (rc != FNN_OK) return rc;
         }
         ProfScope ps(h, "update", h->st);
-        if (h->bf16) launch_update<bf16_t>(h, h->bucket, h->cfg.lr); else launch_update<float>(h, h->bucket, h->cfg.lr);
+        BY_PREC(h, launch_update, (h, h->bucket, h->cfg.lr));
     }
     HIPCHK(h, hipGetLastError());
     h->in_step = false;
@@ -1264,8 +1267,7 @@ int fnn_predict(fnn_handle* h, const int32_t* ids, int B, float* p_out, int memk
         HIPCHK(h, hipMemcpyAsync(h->st_ids, ids, (size_t)B * h->F * 4, hipMemcpyHostToDevice, h->st));
         ids_d = h->st_ids; p_d = h->st_p;
     }
-    rc = h->bf16 ? run_step<bf16_t>(h, ids_d, nullptr, B, nullptr, nullptr, false, p_d, nullptr)
-                 : run_step<float>(h, ids_d, nullptr, B, nullptr, nullptr, false, p_d, nullptr);
+    rc = BY_PREC_RC(h, run_step, (h, ids_d, nullptr, B, nullptr, nullptr, false, p_d, nullptr));
     if (rc != FNN_OK) return rc;
     HIPCHK(h, hipGetLastError());
     if (memkind == FNN_MEM_HOST) {
@@ -1294,8 +1296,7 @@ int fnn_eval(fnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, int
     if (p_out && !host) p_d = p_out; else EK(hipMalloc((void**)&p_d, (size_t)N * 4));
     for (int64_t lo = 0; lo < N; lo += h->Bmax) {
         const int B = (int)std::min<int64_t>(h->Bmax, N - lo);
-        rc = h->bf16 ? run_step<bf16_t>(h, ids_d + lo * h->F, nullptr, B, nullptr, nullptr, false, p_d + lo, nullptr)
-                     : run_step<float>(h, ids_d + lo * h->F, nullptr, B, nullptr, nullptr, false, p_d + lo, nullptr);
+        rc = BY_PREC_RC(h, run_step, (h, ids_d + lo * h->F, nullptr, B, nullptr, nullptr, false, p_d + lo, nullptr));
         if (rc != FNN_OK) { cleanup(); return rc; }
     }
     EK(hipGetLastError());

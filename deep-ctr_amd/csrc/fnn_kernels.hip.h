@@ -33,7 +33,34 @@ constexpr int SLOT = 16;            // padded row width (floats) of the FM table
 constexpr int ACT_TANH = 0, ACT_SIGMOID = 1, ACT_LINEAR = 2;
 constexpr double FIX_SCALE = 17592186044416.0;  // 2^44: fixed-point scale of the scatter sums
 
+// FNN_PREC_BF16X3: every operand element is a PAIR of bf16 values, hi = bf16(v) and lo = bf16(v - hi) (16 significant bits),
+// and a product is three bf16 MFMAs, hi*hi + hi*lo + lo*hi with f32 accumulation -- 4.4x the rate of the exact-f32 MFMA on this
+// part (tools/exp/mma_split_bench.hip: 144 against 640 ticks per five 16x16 tiles of k = 16) at an error 430x below plain bf16's
+// (6.7e-5 against 2.9e-2 on a K = 256 dot product of uniform values whose f32-MFMA error is 9.5e-6).  The element is 4 bytes, so
+// every layout of the f32 mode (EPL = 4, KS = 16, ft_off, LDS tiles) holds unchanged; only `mma` differs.
+__host__ __device__ inline unsigned bs_pack(const float v) {              // hi in the low half, lo in the high half
+    const bf16_t h = (bf16_t)v;
+    const bf16_t l = (bf16_t)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | (unsigned)__builtin_bit_cast(unsigned short, l) << 16;
+}
+__host__ __device__ inline float bs_unpack(const unsigned u) {
+    return __builtin_bit_cast(float, u << 16) + __builtin_bit_cast(float, u & 0xffff0000u);
+}
+struct alignas(4) bs16_t {
+    unsigned short hi, lo;
+    bs16_t() = default;
+    __host__ __device__ explicit bs16_t(float v) { const unsigned u = bs_pack(v); hi = (unsigned short)(u & 0xffffu); lo = (unsigned short)(u >> 16); }
+    __host__ __device__ explicit operator float() const { return bs_unpack((unsigned)hi | (unsigned)lo << 16); }
+};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct Traits;
+template <> struct Traits<bs16_t> {
+    typedef u32x4 frag;             // four elements: dword = hi | lo << 16
+    static constexpr int EPL = 4;
+    static constexpr int KS = 16;
+};
 template <> struct Traits<float> {
     typedef f32x4 frag;
     static constexpr int EPL = 4;   // elements per lane per fragment (16 B)
@@ -58,6 +85,19 @@ __device__ inline void mma(f32x4& acc, const f32x4 a, const f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// bs16_t: the same lane map as the f32 form (lane l holds k = 4*(l>>4) + j, j < 4) is the operand map of
+// v_mfma_f32_16x16x16_bf16; the hi and lo planes of a fragment are two v_perm_b32 each.  The small terms are added first.
+__device__ inline void mma(f32x4& acc, const u32x4 a, const u32x4 b) {
+    union { unsigned u[2]; s16x4 s; } ah, al, bh, bl;
+    ah.u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100); ah.u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100);
+    al.u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302); al.u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302);
+    bh.u[0] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100); bh.u[1] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100);
+    bl.u[0] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302); bl.u[1] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bh.s, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bl.s, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh.s, acc, 0, 0, 0);
 }
 
 // Fragment-tiled operand layout for a [rows][Ktot] operand whose k index is the contraction index:
@@ -94,6 +134,9 @@ __device__ inline void store4(bf16_t* p, float a, float b, float c, float d) {
     bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
     *reinterpret_cast<bf16x4*>(p) = v;
 }
+__device__ inline void store4(bs16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{bs_pack(a), bs_pack(b), bs_pack(c), bs_pack(d)};
+}
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains every global
 // load and store in flight (s_waitcnt vmcnt(0)), which would serialise the strip kernel's
 // weight prefetch and its activation stores behind each phase barrier; the waves of a strip
@@ -106,6 +149,11 @@ __device__ inline float4 load4(const bf16_t* p) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
+__device__ inline float4 load4(const bs16_t* p) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);         // (plain integer unpacking: a bit_cast of a vector ELEMENT to the
+    return make_float4(bs_unpack(v[0]), bs_unpack(v[1]), bs_unpack(v[2]), bs_unpack(v[3]));   // struct read element 0 four times)
+}
+
 // tanh for the bf16 mode: 1 - 2/(exp(2z)+1) with the hardware exp (abs. error ~1e-7, far below
 // bf16's 2^-9); the f32 parity mode keeps libm's tanhf.
 template <typename T> __device__ inline float tanh_t(float z) { return tanhf(z); }
@@ -113,6 +161,7 @@ template <> __device__ inline float tanh_t<bf16_t>(float z) {
     const float e = __expf(2.0f * fminf(fmaxf(z, -15.f), 15.f));
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);     // v_exp + v_rcp, no IEEE divide
 }
+template <> __device__ inline float tanh_t<bs16_t>(float z) { return tanh_t<bf16_t>(z); }      // 1e-7 is below 2^-17 as well
 // logistic function: hardware exp + reciprocal (rel. error ~1e-7; z clamped so exp stays finite)
 __device__ inline float sigmoid_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-fminf(fmaxf(z, -80.f), 80.f)));
@@ -607,6 +656,36 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
     f32x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 4) {
+        // the 4-byte element types walk twice as many k-steps as bf16 for the same slice: a ring of D k-steps of both operands in
+        // registers (loads past the end re-read the last k-step: no branch in the loop), instead of one round trip per 4 k-steps
+        constexpr int D = 6;
+        frag ra[D], rb[D][4];
+        auto ld = [&](const int j, const int kt) {
+            const int k = kt0 + min(kt, nkt - 1);
+            ra[j] = *reinterpret_cast<const frag*>(ft_frag<T>(A, rt, k, nkt_all, lane));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rb[j][n] = *reinterpret_cast<const frag*>(ft_frag<T>(B, ct0 + n, k, nkt_all, lane));
+        };
+#pragma unroll
+        for (int j = 0; j < D; ++j) ld(j, j);
+        int kt = 0;
+        for (; kt + D <= nkt; kt += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma(acc[n], ra[j], rb[j][n]);
+                ld(j, kt + D + j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (kt + j < nkt) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma(acc[n], ra[j], rb[j][n]);
+            }
+        }
+    } else {
 #pragma unroll 4
     for (int kt = 0; kt < nkt; ++kt) {
         const frag af = *reinterpret_cast<const frag*>(ft_frag<T>(A, rt, kt0 + kt, nkt_all, lane));
@@ -615,6 +694,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
             const frag bf = *reinterpret_cast<const frag*>(ft_frag<T>(B, ct0 + n, kt0 + kt, nkt_all, lane));
             mma(acc[n], af, bf);
         }
+    }
     }
     float* o = pr.out + (size_t)by * zstride;
     const int r0 = rt * 16 + 4 * (lane >> 4);
@@ -672,6 +752,36 @@ template <typename T> struct MlpArgs {
 #endif
 
 // BAG = false: layer one is the concatenation of the F gathered FM rows (FNN, :87-96).
+// Weight stream of one product phase for the 4-byte element types (f32, bf16 pairs), whose whole-phase register prefetch (PF
+// below) would not fit: a ring of D k-steps of B fragments in registers.  The first D k-steps are requested one phase AHEAD
+// (`head`, like PF), the others D k-steps ahead inside the fully unrolled loop -- without it every k-step of these modes paid an
+// L2 round trip for its C fragments (step1: 68 us in f32 against 20.5 in bf16 for twice the bytes and 1/16 of the MFMA rate).
+template <typename T, int C, int D> struct WRing { typename Traits<T>::frag s[D][C]; };
+template <int C> constexpr int wring_depth(int nk) { return (20 / C) < nk ? (20 / C) : nk; }
+template <typename T, int NK, int C, int D>
+__device__ __forceinline__ void wring_head(WRing<T, C, D>& r, const T* __restrict__ W, const int rt0, const int lane) {
+    typedef typename Traits<T>::frag frag;
+#pragma unroll
+    for (int kk = 0; kk < D; ++kk)
+#pragma unroll
+        for (int i = 0; i < C; ++i) r.s[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk, NK, lane));
+}
+template <typename T, int NK, int C, int D>
+__device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r, const T* ap, const T* __restrict__ W, const int rt0, const int lane) {
+    typedef typename Traits<T>::frag frag;
+    constexpr int KS = Traits<T>::KS;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+#pragma unroll
+        for (int i = 0; i < C; ++i) mma(acc[i], af, r.s[kk % D][i]);
+        if (kk + D < NK) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) r.s[kk % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + D, NK, lane));
+        }
+    }
+}
+
 // BAG = true : layer one is x = sigmoid(sum of the F gathered rows of ww0 + bb0), rw floats wide
 //              (SNN, python/SNN_RBM.py:248-256), and the kernel returns
 //              delta = gx * x * (1 - x) (:288-290) instead of gx.
@@ -726,13 +836,15 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     constexpr bool PF = sizeof(T) == 2;
     constexpr int NK1 = K1p / KS, NKH1 = H1p / KS, NKH2 = H2p / KS;
     frag b1[PF ? NK1 : 1][PF ? C1 : 1];
+    constexpr int DR1 = wring_depth<C1>(NK1), DR2 = wring_depth<C2>(NKH1), DR3 = wring_depth<C1>(NKH2), DR4 = wring_depth<CX>(NKH1);
+    WRing<T, C1, PF ? 1 : DR1> r1;
     if constexpr (PF) {
 #pragma unroll
         for (int kk = 0; kk < NK1; ++kk)
 #pragma unroll
             for (int i = 0; i < C1; ++i)
                 b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
-    }
+    } else wring_head<T, NK1, C1, DR1>(r1, a.w1t, wave * C1, lane);
 
     if constexpr (BAG) {
         // ---- P0 (bag): x = sigmoid(sum_f ww0[id_f] + bb0).  ids of the strip first (one per thread),
@@ -839,29 +951,27 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     // ---- P1: d1 = act(x' W1p) * r1   (:147-155)
     float d1v[C1][4];
     frag b2[PF ? NKH1 : 1][PF ? C2 : 1];
+    WRing<T, C2, PF ? 1 : DR2> r2;
     if constexpr (PF) {
 #pragma unroll
         for (int kk = 0; kk < NKH1; ++kk)
 #pragma unroll
             for (int i = 0; i < C2; ++i)
                 b2[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, NKH1, lane));
-    }
+    } else wring_head<T, NKH1, C2, DR2>(r2, a.w2t, wave * C2, lane);
     {
         f32x4 acc[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sx + lr * LX + lq * EPL;
+        if constexpr (PF) {
 #pragma unroll
-        for (int kk = 0; kk < NK1; ++kk) {
-            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+            for (int kk = 0; kk < NK1; ++kk) {
+                const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
-            for (int i = 0; i < C1; ++i) {
-                frag bf;
-                if constexpr (PF) bf = b1[kk][i];
-                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
-                mma(acc[i], af, bf);
+                for (int i = 0; i < C1; ++i) mma(acc[i], af, b1[kk][i]);
             }
-        }
+        } else wring_product<T, NK1, C1, DR1>(acc, r1, ap, a.w1t, wave * C1, lane);
         FNN_STAMP(2);
         // m1v is 0 outside the real columns, so act(z)*m + [col == H1] is the ones column / padding too
         const ActCoef ac1 = act_coef(a.act1);
@@ -888,6 +998,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     // ---- P2: d2 = act2(d1 W2p) * r2, z3 = d2 . w3p   (:164-169)
     float d2v[C2][4], zp[4] = {0.f, 0.f, 0.f, 0.f};
     frag b3[PF ? NKH2 : 1][PF ? C1 : 1];
+    WRing<T, C1, PF ? 1 : DR3> r3;
     if constexpr (PF) {
         if (a.train) {
 #pragma unroll
@@ -896,23 +1007,20 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 for (int i = 0; i < C1; ++i)
                     b3[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, NKH2, lane));
         }
-    }
+    } else { if (a.train) wring_head<T, NKH2, C1, DR3>(r3, a.w2, wave * C1, lane); }
     {
         f32x4 acc[C2];
 #pragma unroll
         for (int i = 0; i < C2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sd1 + lr * L1 + lq * EPL;
+        if constexpr (PF) {
 #pragma unroll
-        for (int kk = 0; kk < NKH1; ++kk) {
-            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+            for (int kk = 0; kk < NKH1; ++kk) {
+                const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
-            for (int i = 0; i < C2; ++i) {
-                frag bf;
-                if constexpr (PF) bf = b2[kk][i];
-                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, NKH1, lane));
-                mma(acc[i], af, bf);
+                for (int i = 0; i < C2; ++i) mma(acc[i], af, b2[kk][i]);
             }
-        }
+        } else wring_product<T, NKH1, C2, DR2>(acc, r2, ap, a.w2t, wave * C2, lane);
         FNN_STAMP(4);
         const ActCoef ac2 = act_coef(a.act2);
 #pragma unroll
@@ -979,29 +1087,27 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     // ---- P3: delta1 = (delta2 W2p^T) * r1 * act'(d1)
     T* sdl1 = sx;                                       // the x' tile is dead since P1
     frag b4[PF ? NKH1 : 1][PF ? CX : 1];
+    WRing<T, CX, PF ? 1 : DR4> r4;
     if constexpr (PF) {
 #pragma unroll
         for (int kk = 0; kk < NKH1; ++kk)
 #pragma unroll
             for (int i = 0; i < CX; ++i)
                 b4[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, NKH1, lane));
-    }
+    } else wring_head<T, NKH1, CX, DR4>(r4, a.w1, wave * CX, lane);
     {
         f32x4 acc[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl2 + lr * L2 + lq * EPL;
+        if constexpr (PF) {
 #pragma unroll
-        for (int kk = 0; kk < NKH2; ++kk) {
-            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+            for (int kk = 0; kk < NKH2; ++kk) {
+                const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
-            for (int i = 0; i < C1; ++i) {
-                frag bf;
-                if constexpr (PF) bf = b3[kk][i];
-                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, NKH2, lane));
-                mma(acc[i], af, bf);
+                for (int i = 0; i < C1; ++i) mma(acc[i], af, b3[kk][i]);
             }
-        }
+        } else wring_product<T, NKH2, C1, DR3>(acc, r3, ap, a.w2, wave * C1, lane);
         FNN_STAMP(7);
         const ActCoef ac1 = act_coef(a.act1);
 #pragma unroll
@@ -1026,17 +1132,14 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < CX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const T* ap = sdl1 + lr * L1 + lq * EPL;
+        if constexpr (PF) {
 #pragma unroll
-        for (int kk = 0; kk < NKH1; ++kk) {
-            const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
+            for (int kk = 0; kk < NKH1; ++kk) {
+                const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
 #pragma unroll
-            for (int i = 0; i < CX; ++i) {
-                frag bf;
-                if constexpr (PF) bf = b4[kk][i];
-                else bf = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, NKH1, lane));
-                mma(acc[i], af, bf);
+                for (int i = 0; i < CX; ++i) mma(acc[i], af, b4[kk][i]);
             }
-        }
+        } else wring_product<T, NKH1, CX, DR4>(acc, r4, ap, a.w1, wave * CX, lane);
         FNN_STAMP(9);
 #pragma unroll
         for (int i = 0; i < CX; ++i) {

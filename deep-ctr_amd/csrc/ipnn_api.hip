@@ -1242,6 +1242,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         cfg->max_batch < 1 || cfg->max_batch > 4096 || !(cfg->keep_prob > 0.f && cfg->keep_prob <= 1.f)) {
         g_ip_err = "bad shape (2..32 fields, k <= 16, 1..8 hidden layers, batch <= 4096, 0 < keep_prob <= 1)"; return FNN_ERR_ARG; }
     if (cfg->act != A_TANH && cfg->act != A_SIG && cfg->act != A_RELU) { g_ip_err = "bad act"; return FNN_ERR_ARG; }
+    if (cfg->precision != FNN_PREC_F32 && cfg->precision != FNN_PREC_BF16) { g_ip_err = "bad precision (FNN_PREC_F32 or FNN_PREC_BF16; FNN_PREC_BF16X3 is the FNN / SNN engine's)"; return FNN_ERR_ARG; }
     if (cfg->optimizer != IPNN_OPT_SGD && cfg->optimizer != IPNN_OPT_ADAM && cfg->optimizer != IPNN_OPT_FTRL) { g_ip_err = "bad optimizer"; return FNN_ERR_ARG; }
     if (cfg->optimizer == IPNN_OPT_ADAM && !(cfg->adam_eps > 0.f)) { g_ip_err = "Adam needs adam_eps > 0"; return FNN_ERR_ARG; }
     int ndev = 0;

@@ -588,6 +588,7 @@ int rbm_dense_create(int nvis, int nhid, int max_n, int precision, int device, v
     if (!out) RFAIL(FNN_ERR_ARG, "null out");
     *out = nullptr;
     if (nvis < 1 || nvis > 4095 || nhid < 1 || nhid > 4095 || max_n < 1) RFAIL(FNN_ERR_ARG, "bad shape");
+    if (precision != FNN_PREC_F32 && precision != FNN_PREC_BF16) RFAIL(FNN_ERR_ARG, "bad precision (FNN_PREC_F32 or FNN_PREC_BF16)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
     if (device < 0 || device >= ndev) RFAIL(FNN_ERR_ARG, "device ordinal out of range");

@@ -24,7 +24,8 @@ class FNNEngine(object):
     """One handle = one GPU + one HIP stream.
 
     Parameters follow python/FNN_wnzh.py:18-49: hidden1, hidden2, lr, lambda1, lambda_fm, acti_type.
-    precision: 'f32' (parity mode) or 'bf16' (throughput mode).
+    precision: 'f32' (parity mode: exact-f32 MFMA), 'bf16' (throughput mode) or 'bf16x3' (operands as bf16 pairs, three bf16
+    MFMAs per product: 16 significant bits at 4.4x the f32 MFMA rate -- FNN_PREC_BF16X3 of include/fnn_hip.h).
     """
 
     def __init__(self, n_fields=16, k=11, hidden1=300, hidden2=100, max_batch=4096, precision='bf16',
@@ -46,7 +47,7 @@ class FNNEngine(object):
         self.max_batch = max_batch
         self.precision = precision
         cfg = _capi.fnn_cfg(n_fields, k, hidden1, hidden2, max_batch,
-                            _capi.FNN_PREC_BF16 if precision == 'bf16' else _capi.FNN_PREC_F32,
+                            _capi.PRECISIONS[precision],
                             _ACTS[acti_type], 1 if reg_all else 0, lr, lambda1, lambda_fm, device,
                             C.c_void_p(self.stream.cuda_stream),
                             _capi.FNN_MODE_BAG if self.bag else _capi.FNN_MODE_FM, hidden0)

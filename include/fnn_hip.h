@@ -45,6 +45,9 @@ extern "C" {
 
 #define FNN_PREC_F32    0   /* exact-f32 MFMA; the parity mode               */
 #define FNN_PREC_BF16   1   /* bf16 MFMA inputs, f32 accumulate, f32 masters */
+#define FNN_PREC_BF16X3 2   /* operands as bf16 pairs (hi + lo, 16 significant bits), three bf16 MFMAs per product, f32
+                               accumulate, f32 masters: 4.4x the exact-f32 MFMA rate, error ~7x f32's (430x below bf16's);
+                               the FNN / SNN engine only (fnn_create) */
 
 #define FNN_ACT_TANH    0   /* acti_type, python/FNN_wnzh.py:23,148-163      */
 #define FNN_ACT_SIGMOID 1
