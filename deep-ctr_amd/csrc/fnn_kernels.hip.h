@@ -100,6 +100,33 @@ __device__ inline void mma(f32x4& acc, const u32x4 a, const u32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh.s, acc, 0, 0, 0);
 }
 
+// One A fragment against C B fragments (C independent accumulators).  The bf16-pair form issues its three terms TERM-major --
+// the small terms of all C tiles, then the large one -- so that an MFMA never waits for the one before it (at one wave per
+// SIMD the three dependent MFMAs of `mma` cost 56 ticks per tile, 29 when other work sits between them).
+template <int C, typename F>
+__device__ __forceinline__ void mma_row(f32x4 (&acc)[C], const F a, const F (&b)[C]) {
+#pragma unroll
+    for (int i = 0; i < C; ++i) mma(acc[i], a, b[i]);
+}
+template <int C>
+__device__ __forceinline__ void mma_row(f32x4 (&acc)[C], const u32x4 a, const u32x4 (&b)[C]) {
+    union P { unsigned u[2]; s16x4 s; };
+    P ah, al, bh[C], bl[C];
+    ah.u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100); ah.u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100);
+    al.u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302); al.u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        bh[i].u[0] = __builtin_amdgcn_perm(b[i][1], b[i][0], 0x05040100); bh[i].u[1] = __builtin_amdgcn_perm(b[i][3], b[i][2], 0x05040100);
+        bl[i].u[0] = __builtin_amdgcn_perm(b[i][1], b[i][0], 0x07060302); bl[i].u[1] = __builtin_amdgcn_perm(b[i][3], b[i][2], 0x07060302);
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al.s, bh[i].s, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bl[i].s, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh[i].s, acc[i], 0, 0, 0);
+}
+
 // Fragment-tiled operand layout for a [rows][Ktot] operand whose k index is the contraction index:
 // element (row, k) lives at ((row/16 * Ktot/KS + k/KS) * 64 + lane) * EPL + k % EPL with
 // lane = row%16 + 16 * ((k % KS) / EPL)  -- exactly the MFMA operand map above.
@@ -659,7 +686,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
     if constexpr (sizeof(T) == 4) {
         // the 4-byte element types walk twice as many k-steps as bf16 for the same slice: a ring of D k-steps of both operands in
         // registers (loads past the end re-read the last k-step: no branch in the loop), instead of one round trip per 4 k-steps
-        constexpr int D = 6;
+#ifndef FNN_WGRAD_RING
+#define FNN_WGRAD_RING 6
+#endif
+        constexpr int D = FNN_WGRAD_RING;
         frag ra[D], rb[D][4];
         auto ld = [&](const int j, const int kt) {
             const int k = kt0 + min(kt, nkt - 1);
@@ -674,7 +704,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
 #pragma unroll
             for (int j = 0; j < D; ++j) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma(acc[n], ra[j], rb[j][n]);
+                for (int n = 0; n < 4; ++n) mma(acc[n], ra[j], rb[j][n]);      // (term-major issue, mma_row, measured slower here: 18.2 -> 22.4 us)
                 ld(j, kt + D + j);
             }
         }
@@ -757,7 +787,10 @@ template <typename T> struct MlpArgs {
 // (`head`, like PF), the others D k-steps ahead inside the fully unrolled loop -- without it every k-step of these modes paid an
 // L2 round trip for its C fragments (step1: 68 us in f32 against 20.5 in bf16 for twice the bytes and 1/16 of the MFMA rate).
 template <typename T, int C, int D> struct WRing { typename Traits<T>::frag s[D][C]; };
-template <int C> constexpr int wring_depth(int nk) { return (20 / C) < nk ? (20 / C) : nk; }
+#ifndef FNN_WRING_FRAGS
+#define FNN_WRING_FRAGS 30            // fragments of a ring: D = FNN_WRING_FRAGS / C k-steps in flight
+#endif
+template <int C> constexpr int wring_depth(int nk) { return (FNN_WRING_FRAGS / C) < nk ? (FNN_WRING_FRAGS / C) : nk; }
 template <typename T, int NK, int C, int D>
 __device__ __forceinline__ void wring_head(WRing<T, C, D>& r, const T* __restrict__ W, const int rt0, const int lane) {
     typedef typename Traits<T>::frag frag;
@@ -773,8 +806,7 @@ __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
-#pragma unroll
-        for (int i = 0; i < C; ++i) mma(acc[i], af, r.s[kk % D][i]);
+        mma_row<C>(acc, af, r.s[kk % D]);
         if (kk + D < NK) {
 #pragma unroll
             for (int i = 0; i < C; ++i) r.s[kk % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + D, NK, lane));

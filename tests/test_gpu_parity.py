@@ -797,7 +797,10 @@ def test_snn_full_shape_reproducible(built):
         touched = np.unique(ids)
         res.append((eng.get_rows(touched), eng.get_bag_bias(), eng.get_rows(np.array([5, 77777, 500000]))))
         eng.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    nd = int((res[0][0] != res[1][0]).sum())
+    assert nd == 0, "touched rows differ between two runs: %d values in %d rows, max |d| %.3e" % (
+        nd, int((res[0][0] != res[1][0]).any(axis=1).sum()), float(np.abs(res[0][0] - res[1][0]).max()))
+    assert np.array_equal(res[0][1], res[1][1]), "bag bias differs between two runs: max |d| %.3e" % float(np.abs(res[0][1] - res[1][1]).max())
     untouched = np.setdiff1d(np.array([5, 77777, 500000]), np.unique(ids))
     for i, r in enumerate([5, 77777, 500000]):
         if r in untouched:
