@@ -759,6 +759,9 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
             else if (h->split) { const bs16_t one(1.0f); memcpy(&ones[ft_off<bs16_t>(0, (int)t, (int)Ba) * 4], &one, 4); }
             else { const float one = 1.0f; memcpy(&ones[ft_off<float>(0, (int)t, (int)Ba) * 4], &one, 4); }
         }
+        // alloc_dev zeroes with hipMemsetAsync on the handle's (non-blocking) stream, which a null-stream hipMemcpy does not
+        // wait for: without this sync the zeroing could land AFTER the copy (seen as a bag bias that never moved, one run in a few)
+        HK(hipStreamSynchronize(h->st));
         HK(hipMemcpy(h->onesT, ones.data(), ones.size(), hipMemcpyHostToDevice));
     }
     h->key64 = true;                                                  // refined when the table is set
