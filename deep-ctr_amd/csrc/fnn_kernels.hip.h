@@ -683,7 +683,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
     f32x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (sizeof(T) == 4) {
+#ifndef FNN_WGRAD_RING_BF16
+#define FNN_WGRAD_RING_BF16 0      // measured with 1: the bf16 step's second launch 16.5 -> 17.9 us (SNN 24.6 -> 26.3): bf16 keeps the unroll-4 loop
+#endif
+    if constexpr (sizeof(T) == 4 || FNN_WGRAD_RING_BF16) {
         // the 4-byte element types walk twice as many k-steps as bf16 for the same slice: a ring of D k-steps of both operands in
         // registers (loads past the end re-read the last k-step: no branch in the loop), instead of one round trip per 4 k-steps
 #ifndef FNN_WGRAD_RING
