@@ -239,7 +239,7 @@ struct Finder {
 }  // namespace
 
 struct ctr_fm_model {
-    int k = 0, n_fields = 0; double w0 = 0.0;
+    int k = 0, n_fields = 0; double w0 = 0.0; bool from_file = false;     // from_file: `rows` is meaningful (possibly empty)
     std::vector<int64_t> feat; std::vector<int32_t> field; std::vector<double> rows;
     IdMap map;                                               // while the model is being put together (later lines overwrite)
     Finder finder;                                           // what the line parser reads
@@ -293,14 +293,15 @@ int ctr_fm_model_load(const char* path, const char* const* field_names, int n_fi
                 while (i < e && !is_ws(g.p[i])) ++i;
                 tok.push_back(Tok{g.p + b, g.p + i});
             }
-            int64_t feat;
-            if ((int)tok.size() < 2 + k) { err.set(ln, CTR_ERR_PARSE, "too few tokens (IndexError)"); return; }
+            int64_t feat;                                     // python/data_fm.py:39-43, in that order
             if (!py_int(tok[0].b, tok[0].e, feat)) { err.set(ln, CTR_ERR_PARSE, "feature id is not an int"); return; }
             for (int j = 0; j < k; ++j) {
                 double v;
+                if (1 + j >= (int)tok.size()) { err.set(ln, CTR_ERR_INDEX, "line ends before its weights (IndexError)"); return; }
                 if (!py_float(tok[1 + j].b, tok[1 + j].e, v)) { err.set(ln, CTR_ERR_PARSE, "weight is not a float"); return; }
                 pt.w.push_back(v);
             }
+            if (1 + k >= (int)tok.size()) { err.set(ln, CTR_ERR_INDEX, "line ends before its field tag (IndexError)"); return; }
             const Tok tag = tok[1 + k];
             const char* colon = static_cast<const char*>(memchr(tag.b, ':', tag.e - tag.b));
             if (!colon) { err.set(ln, CTR_ERR_PARSE, "field tag has no ':' (ValueError: substring not found)"); return; }
@@ -313,7 +314,7 @@ int ctr_fm_model_load(const char* path, const char* const* field_names, int n_fi
     });
     if (err.code != CTR_OK) return fail(err.code, std::string(path) + ":" + std::to_string(err.line.load()) + ": " + err.msg);
     ctr_fm_model* m = new ctr_fm_model();
-    m->k = k; m->n_fields = n_fields; m->w0 = w0;
+    m->k = k; m->n_fields = n_fields; m->w0 = w0; m->from_file = true;
     size_t total = 0;
     for (auto& pt : parts) total += pt.feat.size();
     if (total >= (size_t)INT32_MAX) { delete m; return fail(CTR_ERR_CAP, "more than 2^31 rows"); }
@@ -365,9 +366,9 @@ double ctr_fm_model_w0(const ctr_fm_model* m) { return m ? m->w0 : 0.0; }
 int ctr_fm_model_copy(const ctr_fm_model* m, double* rows, int64_t* feat_ids, int32_t* field_of_row)
 {
     if (!m) return fail(CTR_ERR_ARG, "null model");
-    if (rows) { if (m->rows.empty()) return fail(CTR_ERR_ARG, "model has no rows (built from arrays)"); memcpy(rows, m->rows.data(), m->rows.size() * sizeof(double)); }
-    if (feat_ids) memcpy(feat_ids, m->feat.data(), m->feat.size() * sizeof(int64_t));
-    if (field_of_row) memcpy(field_of_row, m->field.data(), m->field.size() * sizeof(int32_t));
+    if (rows) { if (!m->from_file) return fail(CTR_ERR_ARG, "model has no rows (built from arrays)"); if (!m->rows.empty()) memcpy(rows, m->rows.data(), m->rows.size() * sizeof(double)); }
+    if (feat_ids && !m->feat.empty()) memcpy(feat_ids, m->feat.data(), m->feat.size() * sizeof(int64_t));
+    if (field_of_row && !m->field.empty()) memcpy(field_of_row, m->field.data(), m->field.size() * sizeof(int32_t));
     return CTR_OK;
 }
 
@@ -461,13 +462,15 @@ int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int
                     slot = rr;
                 }
             } else {
+                // the reference's order of evaluation, so that a line with several defects raises what it raises there:
+                // python/SNN_RBM.py:249-253 -- per pair int(s[f + 1]) (IndexError when the value is missing, ValueError when malformed),
+                // then int(s[f]) of an active pair; the label int(s[0]) LAST (:258).  get_batch_x (rbm_sparse.py:148-151): the value,
+                // then the id, of every pair; s[0] is never read -- a label that is not an int is 0 here, not an error.
                 tokenize(f.p, s, e, false, tok);
-                if (tok.empty() || !py_int(tok[0].b, tok[0].e, y) || y < INT32_MIN || y > INT32_MAX) { err.set(ln, CTR_ERR_PARSE, "label is not an int"); return; }
-                y_out[ex] = (int32_t)y;
-                if ((tok.size() & 1) == 0) { err.set(ln, CTR_ERR_PARSE, "id without a value (IndexError)"); return; }
                 int n = 0;
-                for (size_t j = 1; j + 1 < tok.size(); j += 2) {
+                for (size_t j = 1; j < tok.size(); j += 2) {
                     int64_t feat, val;
+                    if (j + 1 >= tok.size()) { err.set(ln, CTR_ERR_INDEX, "id without a value (IndexError)"); return; }
                     if (!py_int(tok[j + 1].b, tok[j + 1].e, val)) { err.set(ln, CTR_ERR_PARSE, "value is not an int"); return; }
                     if (mode == CTR_MODE_SNN_ACTIVE && val != 1) continue;      // int(s[f]) is only evaluated for active features
                     if (!py_int(tok[j].b, tok[j].e, feat) || feat < INT32_MIN || feat > INT32_MAX) { err.set(ln, CTR_ERR_PARSE, "feature id is not an int32"); return; }
@@ -477,6 +480,9 @@ int ctr_parse_examples_ex(const char* path, int mode, const ctr_fm_model* m, int
                     if (vrow) vrow[n] = (int32_t)val;
                     ++n;
                 }
+                const bool have_y = !tok.empty() && py_int(tok[0].b, tok[0].e, y) && y >= INT32_MIN && y <= INT32_MAX;
+                if (!have_y && mode == CTR_MODE_SNN_ACTIVE) { err.set(ln, CTR_ERR_PARSE, "label is not an int"); return; }
+                y_out[ex] = have_y ? (int32_t)y : 0;
             }
             ++ex;
         }

@@ -11,7 +11,7 @@ import numpy as np
 from . import _capi
 
 MODE_FNN, MODE_SNN_ACTIVE, MODE_PAIRS = 0, 1, 2
-_EXC = {-1: ValueError, -2: IOError, -3: ValueError, -4: KeyError, -5: IndexError}
+_EXC = {-1: ValueError, -2: IOError, -3: ValueError, -4: KeyError, -5: IndexError, -6: IndexError}
 
 
 def n_threads():

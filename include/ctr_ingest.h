@@ -27,9 +27,11 @@ extern "C" {
 #define CTR_OK          0
 #define CTR_ERR_ARG    -1
 #define CTR_ERR_IO     -2   /* IOError: cannot open / map the file                                   */
-#define CTR_ERR_PARSE  -3   /* ValueError / IndexError: int() or float() of a malformed token         */
+#define CTR_ERR_PARSE  -3   /* ValueError: int() or float() of a malformed token                       */
 #define CTR_ERR_KEY    -4   /* KeyError: unknown feature id (FNN_wnzh.py:95) or field name (:82)      */
 #define CTR_ERR_CAP    -5   /* the caller's arrays are too small for the file                         */
+#define CTR_ERR_INDEX  -6   /* IndexError: a token the reference indexes is not there (s[f + 1] of an  */
+                            /* id without a value; a model line that ends before its field tag)       */
 
 /* token rules of the three readers of `y id:val id:val ...` */
 #define CTR_MODE_FNN         0   /* get_fxy: ':' -> ' ', split on whitespace runs, ids = tokens 1,3,5,..;

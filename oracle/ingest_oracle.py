@@ -35,9 +35,7 @@ def parse_fm_model(path):
         if not s:
             continue
         feat = int(s[0])
-        weights = [float(v) for v in s[1:1 + k]]
-        if len(weights) < k:
-            raise IndexError
+        weights = [float(s[1 + i]) for i in range(k)]
         tag = s[1 + k]
         field = NAME_FIELD[tag[0:tag.index(':')]]
         feat_weights[feat] = weights
@@ -76,14 +74,22 @@ def snn_active(path, width=16):
 
 
 def pairs(path, width=16):
+    """get_batch_x: per pair the VALUE is evaluated first, then the id (`x[int(s[f])] = int(s[f+1])`); s[0] is never read there --
+    the label column returned here is int(s[0]) where that parses, else 0."""
     ids, vals, ys = [], [], []
     for line in _lines(path):
         if line.strip() == '':
             continue
         s = line.strip().replace(':', ' ').split(' ')
-        a = [int(s[f]) for f in range(1, len(s), 2)]
-        v = [int(s[f + 1]) for f in range(1, len(s), 2)]
-        ids.append(a + [-1] * (width - len(a))); vals.append(v + [0] * (width - len(v))); ys.append(int(s[0]))
+        a, v = [], []
+        for f in range(1, len(s), 2):
+            val = int(s[f + 1])
+            a.append(int(s[f])); v.append(val)
+        try:
+            y = int(s[0])
+        except ValueError:
+            y = 0
+        ids.append(a + [-1] * (width - len(a))); vals.append(v + [0] * (width - len(v))); ys.append(y)
     return (np.asarray(ids, np.int32).reshape(len(ys), width), np.asarray(vals, np.int32).reshape(len(ys), width),
             np.asarray(ys, np.int32))
 
