@@ -132,3 +132,37 @@ def test_random_fm_model_files(built, tmp_path, text, threads):
     gw0, gk, rows, feat, fo = got[1]
     assert (gw0, gk) == (w0, k) and feat.tolist() == list(fw) and fo.tolist() == [ff[f] for f in fw], text
     assert np.array_equal(rows, np.array([fw[f] for f in fw], np.float64).reshape(len(fw), k), equal_nan=True), text
+
+
+# ---------------------------------------------------------------------------------------------- the yzx readers (A12)
+ytok = st.sampled_from(['5:1', '12:1', '7:0', '3', '40:1:2', '+8:1', 'a:1', ':1', '', '009:1'])
+
+
+@st.composite
+def yzx_file(draw):
+    lines = []
+    for _ in range(draw(st.integers(0, 8))):
+        toks = [draw(st.sampled_from(['0', '1', '1', '-1', 'y'])), draw(st.sampled_from(['0', '300', 'z']))] + draw(st.lists(ytok, min_size=0, max_size=5))
+        lines.append(draw(st.sampled_from(['', ' '])) + draw(st.sampled_from([' ', '\t', '  '])).join(toks[:draw(st.integers(1, len(toks)))]))
+    terms = draw(st.lists(st.sampled_from(['\n', '\n', '\r\n']), min_size=8, max_size=8))
+    return ''.join(l + t for l, t in zip(lines, terms))
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(text=yzx_file(), threads=st.sampled_from([1, 3]))
+def test_random_yzx_files(built, tmp_path, text, threads):
+    """python/ipinyou.py:23-65: `fields = line.strip().split()`, y = int(fields[0]), ids = int(tok.split(':')[0]) of fields[2:]; a
+    line with no feature makes stat's max() raise ValueError; a blank line is an IndexError (fields[0])."""
+    p = tmp_path / 'y.txt'
+    p.write_bytes(text.encode())
+    want = outcome(lambda: io.yzx_stat(str(p)))
+    got = outcome(lambda: ingest.yzx_stat(str(p), threads)[:2])
+    assert got[0] == want[0], (text, got, want)
+    if want[0] == 'err':
+        assert got[1] is want[1], (text, got, want)
+        return
+    assert tuple(got[1]) == tuple(want[1]), text
+    md, mf = want[1]
+    rX, rV, rY = io.yzx_load(str(p), md + 1, mf + 1)
+    X, V, Y = ingest.parse_yzx(str(p), md + 1, mf + 1, threads)
+    assert np.array_equal(X, rX.reshape(X.shape)) and np.array_equal(V, rV.reshape(V.shape)) and np.array_equal(Y, rY), text
