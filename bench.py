@@ -136,7 +136,7 @@ def main():
                     r = fn(*a)
                     return {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline', 'kernel_ms',
                                                   'train_logloss_last_step', 'sparse_minibatch_4096', 'dense_cd1_200x300',
-                                                  'bag_gather_zipf', 'fm_gather', 'phases_s', 'ingest', 'train_examples_per_s',
+                                                  'bag_gather_zipf', 'fm_gather', 'fm_gather_100k', 'bag_gather_100k', 'phases_s', 'ingest', 'train_examples_per_s',
                                                   'eval_examples_per_s') if k in r}
                 except Exception as e:                    # an extra leg must not cost the headline line
                     return {'error': '%s: %s' % (type(e).__name__, e)}
@@ -165,6 +165,8 @@ def main():
                     'standalone_A3_fm_rows': {k: g['fm_gather'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
                     'standalone_A8_bag_rows_uniform_ids': {k: g['roofline'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
                     'standalone_A8_bag_rows_zipf_ids': {k: g['bag_gather_zipf'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids')},
+                    'standalone_A3_fm_rows_100k_per_launch': {k: g['fm_gather_100k'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids', 'examples_per_launch')},
+                    'standalone_A8_bag_rows_uniform_ids_100k_per_launch': {k: g['bag_gather_100k'][k] for k in ('achieved', 'frac', 'unit', 'avg_launch_ms', 'algorithmic_per_example', 'ids', 'examples_per_launch')},
                     'in_step_A3': in_step_gather(args.batch), 'peak': HBM_PEAK_GBS}
     if out is not None:
         print(json.dumps(out))
@@ -704,9 +706,12 @@ def bench_gather(args):
               # every slot draws from the WHOLE table (the bag gather ignores fields): 262k distinct 800-byte rows per launch
               'uniform': np.random.default_rng(7).integers(0, sum(sizes), (NB * B, F), dtype=np.int64).astype(np.int32)}
     res = {}
-    for name, per_ex, dist in (('fm', 64 + 704 + 708, 'zipf'), ('bag', 64 + 16 * 800 + 800, 'uniform'), ('bag_zipf', 64 + 16 * 800 + 800, 'zipf')):
+    # '*_100k': one launch of 100,000 examples, the chunk the reference's evaluation pass gathers at a time (python/FNN_wnzh.py:193-209);
+    # at 16 x 100,000 draws from 937,670 rows a bag row is read about twice per launch
+    for name, per_ex, dist in (('fm', 64 + 704 + 708, 'zipf'), ('bag', 64 + 16 * 800 + 800, 'uniform'), ('bag_zipf', 64 + 16 * 800 + 800, 'zipf'),
+                               ('fm_100k', 64 + 704 + 708, 'zipf'), ('bag_100k', 64 + 16 * 800 + 800, 'uniform')):
         ids = torch.as_tensor(ids_by[dist]).to(dev).contiguous()
-        if name == 'fm':
+        if name.startswith('fm'):
             eng = FNNEngine(F, K, H1, H2, max_batch=B, precision='bf16', device=0)
             eng.set_table(synth.fm_table(sum(sizes), K, 0.05, 1234), fo, -3.0)
             xdim = XDIM
@@ -715,7 +720,7 @@ def bench_gather(args):
             eng.set_table(np.random.default_rng(1).standard_normal((sum(sizes), H0), dtype=np.float32) * np.float32(0.05), fo, 0.0)
             eng.set_bag_bias(np.zeros(H0, np.float32))
             xdim = H0
-        Bk = B
+        Bk = 100000 if name.endswith('_100k') else B
         x = torch.empty((Bk, xdim), dtype=torch.float32, device=dev)
         lib, h = eng.lib, eng.h
 
@@ -750,7 +755,7 @@ def bench_gather(args):
                                '937670 rows, Zipf(1.1) ids'},
         'roofline': dict(res['bag'], kernel='k_bag_ref (A8 gather, uniform ids: every row read misses the caches)', bound='hbm',
                          traffic=None),
-        'bag_gather_zipf': res['bag_zipf'], 'fm_gather': res['fm'],
+        'bag_gather_zipf': res['bag_zipf'], 'fm_gather': res['fm'], 'fm_gather_100k': res['fm_100k'], 'bag_gather_100k': res['bag_100k'],
         'cpu_baseline': None})
 
 

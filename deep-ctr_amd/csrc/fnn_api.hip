@@ -1014,28 +1014,35 @@ int fnn_get_bag_bias(fnn_handle* h, float* bb0_out, int memkind)
 int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memkind)
 {
     if (!h) return FNN_ERR_ARG;
-    if (B <= 0 || B > h->Bmax) FAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
+    // any B: the reference's get_batch_data serves 100,000-line evaluation chunks (python/FNN_wnzh.py:193-221); device pointers
+    // go through one launch, host pointers through the max_batch-sized staging buffers chunk by chunk
+    if (B <= 0 || (size_t)B * h->xdim > (size_t)1 << 40) FAIL(h, FNN_ERR_ARG, "B must be positive");
     if (!h->table16) FAIL(h, FNN_ERR_STATE, "fnn_set_table has not been called");
     if (!ids || !x_out) FAIL(h, FNN_ERR_ARG, "null pointer");
     HIPCHK(h, hipSetDevice(h->dev));
-    const int32_t* ids_dev = ids; float* x_dev = x_out;
-    if (memkind == FNN_MEM_HOST) {
-        HIPCHK(h, hipMemcpyAsync(h->st_ids, ids, (size_t)B * h->F * 4, hipMemcpyHostToDevice, h->st));
-        ids_dev = h->st_ids; x_dev = h->st_x;
-    }
-    const size_t n = (size_t)B * h->xdim;
-    {
-        ProfScope ps(h, "gather_ref", h->st);
-        if (h->bag)
-            hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
-                               h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag);
-        else
-            hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, ids_dev, B, h->F,
-                               h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
-    }
-    if (memkind == FNN_MEM_HOST) {
-        HIPCHK(h, hipMemcpyAsync(x_out, x_dev, n * 4, hipMemcpyDeviceToHost, h->st));
-        return check_async(h);
+    const bool host = memkind == FNN_MEM_HOST;
+    for (int lo = 0; lo < B; lo += host ? h->Bmax : B) {
+        const int nb = host ? std::min(h->Bmax, B - lo) : B;
+        const int32_t* ids_dev = ids + (size_t)lo * h->F; float* x_dev = x_out + (size_t)lo * h->xdim;
+        if (host) {
+            HIPCHK(h, hipMemcpyAsync(h->st_ids, ids + (size_t)lo * h->F, (size_t)nb * h->F * 4, hipMemcpyHostToDevice, h->st));
+            ids_dev = h->st_ids; x_dev = h->st_x;
+        }
+        const size_t n = (size_t)nb * h->xdim;
+        {
+            ProfScope ps(h, "gather_ref", h->st);
+            if (h->bag)
+                hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, ids_dev, nb, h->F,
+                                   h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag);
+            else
+                hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((nb + GR_EX - 1) / GR_EX)), dim3(256), (size_t)GR_EX * (h->xdim + h->F) * sizeof(float), h->st, ids_dev, nb, h->F,
+                                   h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
+        }
+        if (host) {
+            HIPCHK(h, hipMemcpyAsync(x_out + (size_t)lo * h->xdim, x_dev, n * 4, hipMemcpyDeviceToHost, h->st));
+            const int rc = check_async(h);              // (synchronises: the staging buffers are free for the next chunk)
+            if (rc != FNN_OK) return rc;
+        }
     }
     return FNN_OK;
 }

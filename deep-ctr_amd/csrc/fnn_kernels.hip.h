@@ -275,24 +275,50 @@ static __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict
         store4(xpT + ft_off<T>(c0 + j, t0, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
 }
 
-// Reference-layout gather for fnn_gather(): x [B][1+F*K] float (python/FNN_wnzh.py:91-96).
-static __global__ void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
+// Reference-layout gather for fnn_gather(): x [B][1+F*K] float (python/FNN_wnzh.py:91-96).  A workgroup writes GR_EX
+// examples; a thread owns one column (its field and slot are worked out once, not per element -- the first version spent its time
+// in the two integer divisions of a flat index: 47 us for 100,000 examples) and keeps 8 examples' ids, then rows, in flight.
+// The tile of GR_EX x xdim floats goes through LDS and leaves as 16-byte stores over the workgroup's flat range of x (rows of
+// 177 floats start on a 16-byte boundary only every fourth row, the range of 16 rows always does).
+constexpr int GR_EX = 16;
+static __global__ __launch_bounds__(256) void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
                              const float* __restrict__ table16, int64_t n_rows, float w0,
                              float* __restrict__ x, int* __restrict__ err)
 {
+    extern __shared__ __align__(16) unsigned char gr_smem[];
+    float* sx = reinterpret_cast<float*>(gr_smem);                  // [GR_EX][xdim]
     const int xdim = 1 + F * K;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)B * xdim) return;
-    const int t = (int)(gid / xdim), i = (int)(gid % xdim);
-    float v = 0.f;
-    if (i == 0) v = w0;
-    else {
-        const int f = (i - 1) / K, l = (i - 1) % K;
-        int64_t id = ids[(size_t)t * F + f];
-        if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
-        if (id >= 0) v = table16[(size_t)id * SLOT + l];
+    const int t0 = blockIdx.x * GR_EX;
+    int* sids = reinterpret_cast<int*>(sx + GR_EX * xdim);            // [GR_EX][F]: the strip's ids, read once (contiguous)
+    for (int e = threadIdx.x; e < GR_EX * F; e += 256) {
+        int id = -1;
+        if (t0 + e / F < B) {
+            id = ids[(size_t)t0 * F + e];
+            if (id < -1 || id >= n_rows) { atomicOr(err, 1); id = -1; }
+        }
+        sids[e] = id;
     }
-    x[gid] = v;
+    __syncthreads();
+    for (int c = threadIdx.x; c < xdim; c += 256) {
+        const int f = c ? (c - 1) / K : 0, l = c ? (c - 1) % K : 0;
+#pragma unroll
+        for (int e0 = 0; e0 < GR_EX; e0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = c ? sids[(e0 + u) * F + f] : -1;
+                v[u] = id >= 0 ? table16[(size_t)id * SLOT + l] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sx[(e0 + u) * xdim + c] = c ? v[u] : w0;          // x[0] = w_0 (:93)
+        }
+    }
+    __syncthreads();
+    const int nex = min(GR_EX, B - t0);
+    const size_t base = (size_t)t0 * xdim;                          // multiple of 16 floats: 16-byte aligned
+    const int nfl = nex * xdim, n4 = nfl >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(x + base)[i] = reinterpret_cast<const float4*>(sx)[i];
+    for (int i = 4 * n4 + threadIdx.x; i < nfl; i += 256) x[base + i] = sx[i];
 }
 
 // gx' [B][K1p] (slot layout) -> gx [B][1+F*K] (what `train` returns, python/FNN_wnzh.py:179).
@@ -1693,6 +1719,9 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
     }
 }
 
+// (A workgroup-per-16-examples form with the ids staged through LDS, which took the FM-row gather from 47 to 21 us per 100,000
+// examples, was measured on this kernel too and is SLOWER here: 43.8 -> 51.8 us per 16,384 -- one item per thread keeps more row
+// loads in flight.)
 // reference-shaped output of the bag path: x [B][H0] = sigmoid(sum of the F rows + bb0)
 // (python/SNN_RBM.py:248-256).  One thread = 16 bytes of one example's output: its F row pieces are
 // F independent 16-byte loads in flight (the ids of an example are the same for all its threads:

@@ -896,3 +896,18 @@ def test_train_step_above_4096_examples(built, B, max_batch):
         gs = 0.001 * np.abs(g[k]).max()
         np.testing.assert_allclose(d[k], p64[k], rtol=1e-5, atol=2e-3 * gs + 1e-7, err_msg=k)
     eng.close()
+
+
+def test_gather_beyond_max_batch(built):
+    """fnn_gather takes any number of examples (the reference's evaluation pass gathers 100,000 lines at a time,
+    python/FNN_wnzh.py:193-209): one launch for device pointers, max_batch-sized chunks through the staging buffers for host pointers."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(1000, seed=4, empty=[(0, 3), (999, 15)])
+    eng = make_engine(rows, fo, p, max_batch=256)
+    ref = orc.gather(rows.astype(np.float64), ids, -3.0).astype(np.float32)
+    assert np.array_equal(eng.gather(ids).cpu().numpy(), ref)                      # device pointers: 1000 > max_batch = 256
+    import ctypes as C
+    x = np.empty((1000, XDIM), np.float32)
+    ids32 = np.ascontiguousarray(ids, np.int32)
+    rc = eng.lib.fnn_gather(eng.h, ids32.ctypes.data_as(C.c_void_p), 1000, x.ctypes.data_as(C.c_void_p), _capi.FNN_MEM_HOST)
+    assert rc == 0 and np.array_equal(x, ref)                                      # host pointers: four chunks
+    eng.close()
