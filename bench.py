@@ -85,7 +85,7 @@ def main():
                     help='bf16x3 (operands as bf16 pairs, three MFMAs per product): the fnn / snn / e2e workloads')
     ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam', 'ftrl'],
                     help='--workload ipnn only: sgd (BASELINE configs[2]), or the reference family\'s adam / ftrl (dense table pass per step)')
-    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm', 'e2e'],
+    ap.add_argument('--workload', default='fnn', choices=['fnn', 'snn', 'ipnn', 'gather', 'rbm', 'e2e', 'pretrain'],
                     help='fnn: BASELINE configs[1] (default; at N = 1 the other workloads ride along as extra_workloads).  '
                          'snn: the SNN fine-tune step of configs[4] (H0=200 bag rows).  '
                          'ipnn: FNN_IP_L7 train step of configs[2] (7 hidden layers, MFMA stack).  '
@@ -106,14 +106,14 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        if args.workload not in ('fnn', 'snn'):   # (e2e included: one process)
+        if args.workload not in ('fnn', 'snn'):   # (e2e, pretrain included: one process)
             raise SystemExit("--gpus %d: only the fnn / snn steps shard (replicas of %s are not launched)" % (args.gpus, args.workload))
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torchrun: bench.py starts the "
                          "ranks itself)" % (args.gpus, world, args.gpus))
-    if args.precision == 'bf16x3' and args.workload in ('ipnn', 'rbm', 'gather'):
+    if args.precision == 'bf16x3' and args.workload in ('ipnn', 'rbm', 'gather', 'pretrain'):
         raise SystemExit("--precision bf16x3 is the FNN / SNN engine's (workloads fnn, snn, e2e)")
     if args.workload == 'ipnn':
         out = bench_ipnn(args)
@@ -123,6 +123,8 @@ def main():
         out = bench_rbm(args)
     elif args.workload == 'e2e':
         out = bench_e2e(args)
+    elif args.workload == 'pretrain':
+        out = bench_pretrain(args)
     else:
         out = bench_fnn(args, args.precision, args.workload == 'snn')
         if out is not None and world == 1 and args.workload == 'fnn' and not args.no_extras:
@@ -136,7 +138,7 @@ def main():
                     r = fn(*a)
                     return {k: r.get(k) for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline', 'kernel_ms',
                                                   'train_logloss_last_step', 'sparse_minibatch_4096', 'dense_cd1_200x300',
-                                                  'bag_gather_zipf', 'fm_gather', 'fm_gather_100k', 'bag_gather_100k', 'phases_s', 'ingest', 'train_examples_per_s',
+                                                  'bag_gather_zipf', 'fm_gather', 'fm_gather_100k', 'bag_gather_100k', 'dae_online', 'phases_s', 'ingest', 'train_examples_per_s',
                                                   'eval_examples_per_s') if k in r}
                 except Exception as e:                    # an extra leg must not cost the headline line
                     return {'error': '%s: %s' % (type(e).__name__, e)}
@@ -154,6 +156,7 @@ def main():
             ex['fnn_ip_l7'] = leg(bench_ipnn, ip)
             ex['gather'] = leg(bench_gather, short)
             ex['snn_pretrain_rbm'] = leg(bench_rbm, short)
+            ex['fm_and_dae_pretrain'] = leg(bench_pretrain, short)
             e2 = copy.copy(short); e2.e2e_lines = min(args.e2e_lines, 1 << 18)
             ex['fnn_script_epoch_from_text'] = leg(bench_e2e, e2)
             out['extra_workloads'] = ex
@@ -757,6 +760,93 @@ def bench_gather(args):
                          traffic=None),
         'bag_gather_zipf': res['bag_zipf'], 'fm_gather': res['fm'], 'fm_gather_100k': res['fm_100k'], 'bag_gather_100k': res['bag_100k'],
         'cpu_baseline': None})
+
+
+def bench_pretrain(args):
+    """The two pre-trainers of SURVEY 8(f) that had parity tests but no measurement: FM pre-training (row N3: python/FM.py:55-64, a step
+    of batch 4096 at the config shape -- 937,670 features, 16 fields, rank 10, plain SGD with the dense L2 term) and the SNN-DAE online
+    trainers (row N2: sampling_based_denosing_autoencoder.py -- batch 1, sequential by definition, one workgroup each)."""
+    import torch
+    import deep_ctr_amd  # noqa: F401
+    from deep_ctr_amd import _capi, synth
+    lib = _capi.load()
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.Stream(device=dev)
+    st = C.c_void_p(stream.cuda_stream)
+    B, NB = args.batch, 16
+    sizes = synth.field_sizes_ipinyou()
+    D = sum(sizes)
+    # ---------------------------------------------------------------- FM pre-training
+    h = C.c_void_p()
+    if lib.fm_create(F, K, B, 0, st, C.byref(h)) != 0:
+        raise RuntimeError((lib.fm_last_error(None) or b'').decode())
+    rows = synth.fm_table(D, K, 0.01, 77)
+    if lib.fm_set_table(h, rows.ctypes.data, D) != 0 or lib.fm_set_b(h, 0.0) != 0:
+        raise RuntimeError(lib.fm_last_error(h).decode())
+    ids = torch.as_tensor(synth.zipf_ids(NB * B, sizes, 1.1, 99)).to(dev).contiguous()
+    y = torch.as_tensor((np.random.RandomState(3).uniform(size=NB * B) < 0.02).astype(np.float32)).to(dev)
+
+    def fm_steps(n):
+        for i in range(n):
+            j = i % NB
+            rc = lib.fm_train_step(h, ids.data_ptr() + j * B * F * 4, y.data_ptr() + j * B * 4, B, 1e-4, 1e-6, 1, None, None)
+            if rc != 0:
+                raise RuntimeError(lib.fm_last_error(h).decode())
+    with torch.cuda.stream(stream):
+        fm_steps(args.warmup)
+        lib.fm_sync(h)
+        t0 = time.perf_counter()
+        fm_steps(args.steps)
+        lib.fm_sync(h)
+        dt_fm = (time.perf_counter() - t0) / args.steps
+    lib.fm_destroy(h)
+    fm_bytes = 64 + 704 + 704 + 4                                     # ids, rows read, rows written, label
+    # ---------------------------------------------------------------- SNN-DAE online trainers
+    N, H0, H1, S = 20000, 200, 300, 32
+    rng = np.random.default_rng(5)
+    out_dae = {}
+    for prec, npdt, tdt, sfx, lrv in (('f32', np.float32, torch.float32, '', C.c_float(0.1)), ('f64', np.float64, torch.float64, '_f64', C.c_double(0.1))):
+        table = torch.as_tensor(rng.uniform(-0.05, 0.05, (D, H0)).astype(npdt)).to(dev)
+        idx_np = np.sort(synth.zipf_ids(N, sizes, 1.1, 8).astype(np.int64), axis=1)
+        idx2 = np.empty((N, S), np.int32); idx2[:, 0::2] = (idx_np + 1) % D; idx2[:, 1::2] = idx_np      # negative, positive, ...
+        xv = np.zeros((N, S), npdt); xv[:, 1::2] = 1
+        idx_d, x_d = torch.as_tensor(idx2).to(dev), torch.as_tensor(xv).to(dev)
+        bh = torch.zeros(H0, dtype=tdt, device=dev); bv = torch.zeros(S, dtype=tdt, device=dev); bp = torch.zeros(H0, dtype=tdt, device=dev)
+        cost = C.c_double()
+        sp, de = getattr(lib, 'dae_sparse_epoch' + sfx), getattr(lib, 'dae_dense_epoch' + sfx)
+        cs = torch.cuda.current_stream(dev).cuda_stream
+
+        def run_sparse():
+            if sp(table.data_ptr(), D, bh.data_ptr(), bv.data_ptr(), bp.data_ptr(), idx_d.data_ptr(), x_d.data_ptr(), N, H0, S, lrv, C.byref(cost), cs) != 0:
+                raise RuntimeError(lib.dae_last_error().decode())
+        run_sparse(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); run_sparse(); torch.cuda.synchronize(dev)
+        dt_s = time.perf_counter() - t0
+        X = torch.as_tensor(rng.uniform(0, 1, (N, H0)).astype(npdt)).to(dev)
+        W = torch.as_tensor(rng.uniform(-0.1, 0.1, (H0, H1)).astype(npdt)).to(dev)
+        bh2 = torch.zeros(H1, dtype=tdt, device=dev); bv2 = torch.zeros(H0, dtype=tdt, device=dev)
+
+        def run_dense():
+            if de(W.data_ptr(), bh2.data_ptr(), bv2.data_ptr(), X.data_ptr(), N, H0, H1, lrv, 0, C.byref(cost), cs) != 0:
+                raise RuntimeError(lib.dae_last_error().decode())
+        run_dense(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); run_dense(); torch.cuda.synchronize(dev)
+        dt_d = time.perf_counter() - t0
+        out_dae[prec] = {'sparse_layer_examples_per_sec': N / dt_s, 'sparse_layer_us_per_example': dt_s / N * 1e6,
+                         'dense_200x300_examples_per_sec': N / dt_d, 'dense_200x300_us_per_example': dt_d / N * 1e6}
+        del table, X, W
+        torch.cuda.empty_cache()
+    return {
+        'metric': 'examples/sec', 'value': B / dt_fm, 'unit': 'examples/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt_fm * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'FM pre-training step (python/FM.py): 937670 features, 16 fields, rank 10, batch %d, SGD + dense L2, mean loss, '
+                               'Zipf(1.1) ids; beside it the SNN-DAE online trainers (batch 1; %d examples per epoch)' % (B, N)},
+        'roofline': {'kernel': 'fm_train_step (four launches: forward/loss, grouping, two-level sparse-row update)', 'bound': 'hbm',
+                     'achieved': fm_bytes * B / dt_fm / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': fm_bytes * B / dt_fm / 1e9 / HBM_PEAK_GBS,
+                     'traffic': None, 'algorithmic_per_example': fm_bytes, 'note': 'wall time per step (latency-bound like the FNN step)'},
+        'dae_online': dict(out_dae, note='sequential by definition (example n + 1 starts from the parameters example n left): one persistent '
+                                         'workgroup; f64 is what get_da_weights runs by default (the reference\'s floatX)'),
+        'cpu_baseline': None}
 
 
 IP_HIDDEN = [1000, 800, 600, 400, 200, 100, 50]        # python/baseline.py:139 (FNN_IP_L7)
