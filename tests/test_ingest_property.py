@@ -3,7 +3,8 @@ reference's Python expressions restated in oracle/ingest_oracle.py, on RANDOM fi
 unknown and malformed spellings, separators from blanks / tabs / runs / ':' in odd places, every line terminator, blank lines
 anywhere, any thread count.  Either both sides return the same arrays, or both raise -- the native side with the reference's
 exception type.  (Spellings the Python 3 oracle and the Python 2 reference disagree on -- '1_0', non-ASCII digits -- and ids of
-19+ digits, which the native parser reports as malformed, are not generated.)  CPU only."""
+19+ digits, which the native parser reports as malformed, are not generated.)  The draws are derandomised: every run checks the
+same files (a one-off run of 3,000 random files per test found nothing beyond what is fixed here).  CPU only."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -54,7 +55,7 @@ def model(built):
     return ingest.FMModel.from_arrays(np.array(FEATS, np.int64), np.array([FIELD[f] for f in FEATS], np.int32), 3, 16)
 
 
-@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(text=files, threads=st.sampled_from([1, 2, 5]))
 def test_random_files_fnn_mode(model, tmp_path, text, threads):
     p = tmp_path / 'f.txt'
@@ -68,7 +69,7 @@ def test_random_files_fnn_mode(model, tmp_path, text, threads):
         assert got[1] is want[1], (text, got, want)
 
 
-@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(text=files, threads=st.sampled_from([1, 3]))
 def test_random_files_snn_and_pair_modes(built, tmp_path, text, threads):
     p = tmp_path / 'f.txt'
@@ -113,7 +114,7 @@ def model_file(draw):
     return head + terms[0] + ''.join(l + t for l, t in zip(lines, terms[1:])) + draw(st.sampled_from(['', '12 ' + ' '.join(['1'] * (rank + 1)) + ' IP:1']))
 
 
-@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(text=model_file(), threads=st.sampled_from([1, 3]))
 def test_random_fm_model_files(built, tmp_path, text, threads):
     p = tmp_path / 'm.txt'
@@ -148,7 +149,7 @@ def yzx_file(draw):
     return ''.join(l + t for l, t in zip(lines, terms))
 
 
-@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=300, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(text=yzx_file(), threads=st.sampled_from([1, 3]))
 def test_random_yzx_files(built, tmp_path, text, threads):
     """python/ipinyou.py:23-65: `fields = line.strip().split()`, y = int(fields[0]), ids = int(tok.split(':')[0]) of fields[2:]; a
