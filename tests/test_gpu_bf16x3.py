@@ -110,3 +110,27 @@ def test_demo_epochs_bf16x3_logloss_auc_within_1e4(built, golden_dir):
     except OSError:
         pass
     assert max(d.values()) <= 1e-4
+
+
+def test_bf16x3_data_parallel_and_eval(built):
+    """The pair precision under the native data-parallel step (RCCL, world size 1: bitwise the plain step) and in the device-side
+    evaluation pass (metrics equal sklearn's on the engine's own predictions)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    from deep_ctr_amd.engine import FNNEngine
+    rows, fo, ids, y, p, r1, r2 = make_problem(2 * 700, seed=51, dup_col=6)
+    kw = dict(prec='bf16x3', lr=0.01, lam1=0.02, lamfm=0.1)
+    plain, dp = make_engine(rows, fo, p, **kw), make_engine(rows, fo, p, **kw)
+    dp.dp_init(0, 1, FNNEngine.dp_unique_id())
+    for s in range(2):
+        sl = slice(s * 700, (s + 1) * 700)
+        a = plain.train_step(ids[sl], y[sl], r1, r2)
+        b = dp.train_step(ids[sl], y[sl], r1, r2, b_size=700)
+        assert a['loss'] == b['loss']
+    da, db = plain.get_dense(), dp.get_dense()
+    assert all(np.array_equal(da[k], db[k]) for k in da) and np.array_equal(plain.get_table(), dp.get_table())
+    dp.dp_shutdown(); dp.close()
+    yy = (np.random.RandomState(6).uniform(size=len(ids)) < 0.3).astype(np.int32)
+    m = plain.evaluate(ids, yy, want_p=True)
+    pp = m['p'].cpu().numpy().astype(np.float64)
+    assert abs(m['auc'] - roc_auc_score(yy, pp)) < 1e-12 and abs(m['logloss'] - log_loss(yy, pp, labels=[0, 1])) < 1e-12
+    plain.close()
