@@ -26,11 +26,10 @@ struct FmArgs {
     float scale, dscale; int train; float* gxp; int K1p; float* p_out; float* loss_t; float* gb_part; int* err;
 };
 
-__global__ __launch_bounds__(256) void k_fm(const FmArgs a)
+__device__ __forceinline__ void fm_body(const FmArgs& a, const int blk, float* s_gb)
 {
-    __shared__ float s_gb[16];
     const int tid = threadIdx.x, f = tid & 15, grp = tid >> 4;
-    const int t = blockIdx.x * 16 + grp;
+    const int t = blk * 16 + grp;
     int64_t id = -1;
     if (t < a.B && f < a.F) {
         id = a.ids[(size_t)t * a.F + f];
@@ -80,20 +79,46 @@ __global__ __launch_bounds__(256) void k_fm(const FmArgs a)
     }
     if (f == 0) s_gb[grp] = delta;
     __syncthreads();
-    if (tid == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += s_gb[i]; a.gb_part[blockIdx.x] = s; }
+    if (tid == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += s_gb[i]; a.gb_part[blk] = s; }
+}
+__global__ __launch_bounds__(256) void k_fm(const FmArgs a)
+{
+    __shared__ float s_gb[16];
+    fm_body(a, blockIdx.x, s_gb);
+}
+// A training step is four launches: run sorts of the batch's (row, t) keys; their rank merge BESIDE the forward + gradients
+// (both need only the ids: the merge takes 16 F workgroups, the examples the rest); level-1 sparse-row update; level-2 update
+// BESIDE the bias / loss tail.  As six launches in a row (sort, sort, forward, scatter, scatter, tail) the step took 49.6 us.
+template <typename KT>
+__global__ __launch_bounds__(256) void k_fm_merge_fwd(const SortArgs so, const FmArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float s_gb[16];
+    if ((int)blockIdx.x < so.nblk) { sortB_body<KT>(so, blockIdx.x, smem); return; }
+    fm_body(a, (int)blockIdx.x - so.nblk, s_gb);
 }
 
 // b <- b (1 - lr lambda) - lr sum(delta); loss sum (fixed-shape tree)
-__global__ void k_fm_tail(float* b, const float* gb_part, int n, float lr, float lambda, const float* loss_t, int Ba, float lscale,
-                          float* loss_out)
-{
-    __shared__ float sl[256];
-    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s += gb_part[i]; *b = *b * (1.0f - lr * lambda) - lr * s; }
-    float v = 0.f;
+__device__ __forceinline__ void fm_tail_body(float* b, const float* gb_part, int n, float lr, float lambda, const float* loss_t, int Ba, float lscale,
+                                             float* loss_out, float* sl)
+{   // both sums as 256 strided partial sums and a fixed-shape tree (one thread walking the n partials paid a memory round trip
+    // per element: 19 us for 256 of them)
+    float v = strided_sum256(gb_part, n);
+    sl[threadIdx.x] = v; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o]; __syncthreads(); }
+    const float gsum = sl[0];
+    __syncthreads();
     v = strided_sum256(loss_t, Ba);
     sl[threadIdx.x] = v; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sl[threadIdx.x] += sl[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) *loss_out = sl[0] * lscale;
+    if (threadIdx.x == 0) { *b = *b * (1.0f - lr * lambda) - lr * gsum; *loss_out = sl[0] * lscale; }
+}
+__global__ __launch_bounds__(256) void k_fm_scat2_tail(const ScatArgs sa, float* b, const float* gb_part, int n, float lr, float lambda,
+                                                       const float* loss_t, int Ba, float lscale, float* loss_out)
+{
+    __shared__ double s_sum[16][16];
+    if (blockIdx.x == 0) { fm_tail_body(b, gb_part, n, lr, lambda, loss_t, Ba, lscale, loss_out, reinterpret_cast<float*>(&s_sum[0][0])); return; }
+    scat2_body(sa, (int)blockIdx.x - 1, (int)gridDim.x - 1, s_sum);
 }
 
 __global__ void k_fm_rescale(float* table16, size_t n, float s)
@@ -131,27 +156,30 @@ int fold_scale(fm_handle* h)          // fold the lazy decay back into the rows
 int fm_run(fm_handle* h, const int32_t* ids, const float* y, int B, float lr, float lambda, int reduce_mean, float* p_out, bool train)
 {
     const int Ba = rup(B, 16), F = h->F;
-    if (train) {
-        SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
-        if (h->key64) {
-            hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, h->st, so);
-            hipLaunchKernelGGL((k_sortB<unsigned long long>), dim3(16 * F), dim3(256), SORT_N * 8, h->st, so);
-        } else {
-            hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, h->st, so);
-            hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, h->st, so);
-        }
-    }
     FmArgs a{ids, y, B, F, h->K, h->table16, h->n_rows, h->b, (float)h->scale, reduce_mean ? 1.0f / (float)B : 1.0f, train ? 1 : 0,
              h->gxp, h->K1p, p_out, h->loss_t, h->gb_part, h->err_flag};
-    hipLaunchKernelGGL(k_fm, dim3(Ba / 16), dim3(256), 0, h->st, a);
-    if (!train) { MHK(h, hipGetLastError()); return FNN_OK; }
+    if (!train) {
+        hipLaunchKernelGGL(k_fm, dim3(Ba / 16), dim3(256), 0, h->st, a);
+        MHK(h, hipGetLastError());
+        return FNN_OK;
+    }
+    {
+        SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, 4 * F, h->skeys};
+        SortArgs sb = so; sb.nblk = 16 * F;
+        if (h->key64) {
+            hipLaunchKernelGGL((k_sortA<unsigned long long>), dim3(4 * F), dim3(256), 0, h->st, so);
+            hipLaunchKernelGGL((k_fm_merge_fwd<unsigned long long>), dim3(16 * F + Ba / 16), dim3(256), SORT_N * 8, h->st, sb, a);
+        } else {
+            hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, h->st, so);
+            hipLaunchKernelGGL((k_fm_merge_fwd<unsigned>), dim3(16 * F + Ba / 16), dim3(256), SORT_N * 4, h->st, sb, a);
+        }
+    }
     // dense L2 decay of the whole table = one scalar; touched rows: stored -= lr * g / scale
     h->scale *= 1.0 - (double)lr * (double)lambda;
     ScatArgs sa{h->rec, SORT_N, F, h->K, h->gxp, h->K1p, h->cpow1, (double)lr / h->scale, h->table16, h->part, h->owner_cnt,
                 h->owners, SLOT};
     hipLaunchKernelGGL(k_scat1, dim3(F * SORT_N / 256), dim3(256), 0, h->st, sa);
-    hipLaunchKernelGGL(k_scat2, dim3(256), dim3(256), 0, h->st, sa);
-    hipLaunchKernelGGL(k_fm_tail, dim3(1), dim3(256), 0, h->st, h->b, h->gb_part, Ba / 16, lr, lambda, h->loss_t, Ba,
+    hipLaunchKernelGGL(k_fm_scat2_tail, dim3(1 + 256), dim3(256), 0, h->st, sa, h->b, h->gb_part, Ba / 16, lr, lambda, h->loss_t, Ba,
                        reduce_mean ? 1.0f / (float)B : 1.0f, h->loss_dev);
     MHK(h, hipGetLastError());
     if (h->scale < 5.96e-8 || h->scale > 1.0) return fold_scale(h);
