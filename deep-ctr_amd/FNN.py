@@ -111,24 +111,17 @@ def run(argv, out=None):
     for i in range(epoch):                                     # :290
         start_time = time.time()
         pre_step = best
-        for j in range(n_batch):                               # :293
-            lo = j * batch_size
-            if lo + 1 > train_size:
-                break
-            ids = train_ids_d[lo:lo + batch_size]              # device-resident slices: no per-batch copies
-            y = train_yf_d[lo:lo + batch_size]
-            if j == n_batch - 1:
-                pre_step = eng.get_dense()                     # `train` returns PRE-update tensors (:298)
-            nlo = (j + 1) * batch_size                         # announce the next batch: its grouping rides on this step's launches
-            if j + 1 < n_batch and nlo + 1 <= train_size and len(y) <= 4096:
-                eng.prefetch_ids(train_ids_d[nlo:nlo + batch_size])
-            if len(train_sh):                                  # lines with two features of one field: both rows are updated (:300-306)
-                a, b = np.searchsorted(train_sh[:, 0], [lo, lo + len(y)])
-                if b > a:
-                    sh = train_sh[a:b].copy()
-                    sh[:, 0] -= lo
-                    eng.set_shadowed(sh)
-            eng.train_step(ids, y, r1.draw()[0], r2.draw()[0], b_size=len(y), want_loss=False)
+        # :293-306.  The epoch's dropout rows are drawn ahead (the same stream: _BinomialOp.draw_rows) and the steps run
+        # through FNNEngine.train_epoch -- resident ids, raw C calls, the next batch announced to every step; `train` returns
+        # PRE-update tensors (:298), so the dense state is read before the last batch
+        n_run = n_batch if (n_batch - 1) * batch_size + 1 <= train_size else (train_size + batch_size - 1) // batch_size
+        m1, m2 = r1.draw_rows(n_run), r2.draw_rows(n_run)
+        if n_run > 1:
+            eng.train_epoch(train_ids_d, train_yf_d, batch_size, m1, m2, 0, n_run - 1, train_sh)
+        if n_run > 0:
+            if n_run == n_batch:
+                pre_step = eng.get_dense()
+            eng.train_epoch(train_ids_d, train_yf_d, batch_size, m1, m2, n_run - 1, 1, train_sh)
         eng.sync()
         print('training: ' + fmt_time(time.time() - start_time))
 

@@ -144,12 +144,10 @@ def run(argv, kind='rbm'):
     hist = []
     for i in range(epoch):
         start_time = time.time()
-        for j in range(n_batch):
-            lo = j * batch_size
-            if j + 1 < n_batch:                                # announce the next batch (grouped beside this step's work)
-                eng.prefetch_ids(train_ids_d[lo + batch_size:lo + 2 * batch_size])
-            eng.train_step(train_ids_d[lo:lo + batch_size], train_yf_d[lo:lo + batch_size], r1.draw()[0], r2.draw()[0],
-                           want_loss=False)
+        # the epoch's dropout rows drawn ahead (same stream), the steps through FNNEngine.train_epoch: resident ids, raw C calls,
+        # the next batch announced to every step (grouped beside this step's work)
+        if n_batch > 0:
+            eng.train_epoch(train_ids_d, train_yf_d, batch_size, r1.draw_rows(n_batch), r2.draw_rows(n_batch), 0, n_batch)
         eng.sync()
         print('training: ' + fmt_time(time.time() - start_time))
         start_time = time.time()

@@ -102,6 +102,12 @@ class _BinomialOp(object):
     def draw(self):
         return self.state.binomial(n=self.n, p=self.p, size=self.size)
 
+    def draw_rows(self, n):
+        """The next n draws of a (1, H) op as one [n, H] array: the legacy RandomState binomial consumes its stream element by
+        element, so one call of size (n, H) IS n calls of size (1, H) (tests/test_host.py holds it to that)."""
+        assert len(self.size) == 2 and self.size[0] == 1
+        return self.state.binomial(n=self.n, p=self.p, size=(n, self.size[1]))
+
 
 def file_len(fname):                                        # python/dl_utils.py:111-115
     with open(fname) as f:

@@ -195,6 +195,47 @@ class FNNEngine(object):
             out['gx'] = gx
         return out
 
+    def train_epoch(self, ids_d, yf_d, batch_size, masks1, masks2, first=0, n_steps=None, shadowed=None):
+        """Steps first .. first + n_steps - 1 of the hot loop (python/FNN_wnzh.py:293-306) over RESIDENT arrays: batch j is rows
+        [j * batch_size, (j + 1) * batch_size) of ids_d int32 [N, F] / yf_d float32 [N] (a short last batch keeps its length as
+        b_size, as the reference's line count does), its dropout rows are row j of masks1 [n, H1] / masks2 [n, H2] (uint8, host or
+        device).  The next batch is announced to every step (fnn_prefetch_ids), `shadowed` (int32 [n, 3] = (example, field, row),
+        sorted by example: DataFM.load_ids(want_shadowed=True)) feeds fnn_set_shadowed per batch.  The loop makes the raw C calls
+        itself: at the reference's batch size of 100 the per-call Python of train_step (~85-120 us) is three times the step."""
+        torch = self._torch
+        assert ids_d.is_cuda and ids_d.dtype == torch.int32 and ids_d.is_contiguous() and yf_d.is_cuda and yf_d.dtype == torch.float32
+        N = ids_d.shape[0]
+        n_all = (N + batch_size - 1) // batch_size
+        n_steps = n_all - first if n_steps is None else n_steps
+        m1, m2 = self._dev(masks1, torch.uint8), self._dev(masks2, torch.uint8)
+        assert m1.shape == (m1.shape[0], self.H1) and m2.shape == (m2.shape[0], self.H2) and min(m1.shape[0], m2.shape[0]) >= first + n_steps
+        lib, h, F = self.lib, self.h, self.F
+        ip, yp, p1, p2 = ids_d.data_ptr(), yf_d.data_ptr(), m1.data_ptr(), m2.data_ptr()
+        sh = None if shadowed is None or len(shadowed) == 0 else np.ascontiguousarray(shadowed, dtype=np.int32)
+        self._enter()
+        for j in range(first, first + n_steps):
+            lo = j * batch_size
+            B = min(batch_size, N - lo)
+            if B <= 0:
+                break
+            nlo = lo + batch_size
+            if j + 1 < first + n_steps and nlo < N and B <= 4096:
+                rc = lib.fnn_prefetch_ids(h, ip + nlo * F * 4, min(batch_size, N - nlo))
+                if rc != 0:
+                    self._ck(rc)
+            if sh is not None:
+                a, b = np.searchsorted(sh[:, 0], [lo, lo + B])
+                if b > a:
+                    part = sh[a:b].copy()
+                    part[:, 0] -= lo
+                    self._ck(lib.fnn_set_shadowed(h, part.ctypes.data, len(part), _capi.FNN_MEM_HOST))
+            rc = lib.fnn_train_step(h, ip + lo * F * 4, yp + lo * 4, B, p1 + j * self.H1, p2 + j * self.H2, B, None, None,
+                                    _capi.FNN_MEM_DEVICE, None)
+            if rc != 0:
+                self._ck(rc)
+        self._leave()
+        self._keep = (ids_d, yf_d, m1, m2)
+
     def set_shadowed(self, tfr):
         """fnn_set_shadowed: int32 [n, 3] = (example t, field, row) of the features that a later feature of the same field
         shadows in the NEXT train_step / step_begin batch; their rows take the sparse update too, as in the reference's loop

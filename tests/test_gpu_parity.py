@@ -911,3 +911,28 @@ def test_gather_beyond_max_batch(built):
     rc = eng.lib.fnn_gather(eng.h, ids32.ctypes.data_as(C.c_void_p), 1000, x.ctypes.data_as(C.c_void_p), _capi.FNN_MEM_HOST)
     assert rc == 0 and np.array_equal(x, ref)                                      # host pointers: four chunks
     eng.close()
+
+
+def test_train_epoch_equals_the_step_loop(built):
+    """FNNEngine.train_epoch (resident arrays, raw C calls, masks drawn ahead, shadowed features per batch) leaves bit for bit the
+    state of the per-step loop it replaces in FNN.py -- full batches, a short last batch, and a start in the middle of the epoch."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(1030, seed=44, dup_col=5)
+    rng = np.random.RandomState(3)
+    M1 = (rng.uniform(size=(11, H1)) < 0.5).astype(np.uint8)
+    M2 = (rng.uniform(size=(11, H2)) < 0.5).astype(np.uint8)
+    sh = np.array([[5, 3, 7], [5, 9, 11], [250, 0, 2], [1029, 15, 900]], np.int32)      # (example, field, row), sorted by example
+    a, b = make_engine(rows, fo, p, lr=0.01, lam1=0.02), make_engine(rows, fo, p, lr=0.01, lam1=0.02)
+    for j in range(11):                                            # 10 batches of 100 and one of 30
+        lo, hi = j * 100, min(1030, (j + 1) * 100)
+        part = sh[(sh[:, 0] >= lo) & (sh[:, 0] < hi)].copy()
+        if len(part):
+            part[:, 0] -= lo
+            a.set_shadowed(part)
+        a.train_step(ids[lo:hi], y[lo:hi], M1[j], M2[j], b_size=hi - lo, want_loss=False)
+    ids_d, y_d = b.to_device(ids, y.astype(np.int32))
+    yf = y_d.float()
+    b.train_epoch(ids_d, yf, 100, M1, M2, 0, 4, sh)                 # in two pieces, as FNN.py reads the dense state before the last batch
+    b.train_epoch(ids_d, yf, 100, M1, M2, 4, None, sh)
+    da, db = a.get_dense(), b.get_dense()
+    assert all(np.array_equal(da[k], db[k]) for k in da) and np.array_equal(a.get_table(), b.get_table())
+    a.close(); b.close()

@@ -315,3 +315,17 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked(built):
     env['WORLD_SIZE'] = '4'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=4' in (r.stderr + r.stdout)
+
+
+def test_mask_rows_drawn_ahead_equal_per_step_draws():
+    """FNN.py draws an epoch's dropout rows in one call (_BinomialOp.draw_rows): the same rows as one draw per `train` call
+    (python/FNN_wnzh.py:154,166 through theano's RandomStreams), for the script's dropout rates."""
+    from deep_ctr_amd import dl_utils as ut
+    for p in (0.5, 0.98, 1.0):
+        a, b = ut.RandomStreams(234), ut.RandomStreams(234)
+        for s in (a, b):
+            s.binomial(size=(1, 177), n=1, p=1)
+        oa, ob = a.binomial(size=(1, 300), n=1, p=p), b.binomial(size=(1, 300), n=1, p=p)
+        seq = np.concatenate([oa.draw() for _ in range(40)] )
+        assert np.array_equal(seq, ob.draw_rows(40))
+        assert np.array_equal(oa.draw(), ob.draw_rows(1))            # and the streams stay in step afterwards
