@@ -127,6 +127,32 @@ __device__ __forceinline__ void mma_row(f32x4 (&acc)[C], const u32x4 a, const u3
     for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah.s, bh[i].s, acc[i], 0, 0, 0);
 }
 
+// Two k-steps of the bf16-pair form at once: the hi (lo) planes of fragments kk and kk + 1 side by side are an operand of
+// v_mfma_f32_16x16x32_bf16 (which k a lane's eight values stand for does not matter as long as A and B agree), at twice the
+// FLOP rate of the 16x16x16 form -- the matrix pipe's share of the strip kernel was 4.8 us of 27 (profiles/r02d_pmc_mfma_*).
+template <int C>
+__device__ __forceinline__ void mma_row2(f32x4 (&acc)[C], const u32x4 a0, const u32x4 a1, const u32x4 (&b0)[C], const u32x4 (&b1)[C]) {
+    union P8 { unsigned u[4]; bf16x8 v; };
+    P8 ah, al, bh[C], bl[C];
+    ah.u[0] = __builtin_amdgcn_perm(a0[1], a0[0], 0x05040100); ah.u[1] = __builtin_amdgcn_perm(a0[3], a0[2], 0x05040100);
+    ah.u[2] = __builtin_amdgcn_perm(a1[1], a1[0], 0x05040100); ah.u[3] = __builtin_amdgcn_perm(a1[3], a1[2], 0x05040100);
+    al.u[0] = __builtin_amdgcn_perm(a0[1], a0[0], 0x07060302); al.u[1] = __builtin_amdgcn_perm(a0[3], a0[2], 0x07060302);
+    al.u[2] = __builtin_amdgcn_perm(a1[1], a1[0], 0x07060302); al.u[3] = __builtin_amdgcn_perm(a1[3], a1[2], 0x07060302);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        bh[i].u[0] = __builtin_amdgcn_perm(b0[i][1], b0[i][0], 0x05040100); bh[i].u[1] = __builtin_amdgcn_perm(b0[i][3], b0[i][2], 0x05040100);
+        bh[i].u[2] = __builtin_amdgcn_perm(b1[i][1], b1[i][0], 0x05040100); bh[i].u[3] = __builtin_amdgcn_perm(b1[i][3], b1[i][2], 0x05040100);
+        bl[i].u[0] = __builtin_amdgcn_perm(b0[i][1], b0[i][0], 0x07060302); bl[i].u[1] = __builtin_amdgcn_perm(b0[i][3], b0[i][2], 0x07060302);
+        bl[i].u[2] = __builtin_amdgcn_perm(b1[i][1], b1[i][0], 0x07060302); bl[i].u[3] = __builtin_amdgcn_perm(b1[i][3], b1[i][2], 0x07060302);
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh[i].v, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl[i].v, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh[i].v, acc[i], 0, 0, 0);
+}
+
 // Fragment-tiled operand layout for a [rows][Ktot] operand whose k index is the contraction index:
 // element (row, k) lives at ((row/16 * Ktot/KS + k/KS) * 64 + lane) * EPL + k % EPL with
 // lane = row%16 + 16 * ((k % KS) / EPL)  -- exactly the MFMA operand map above.
@@ -729,6 +755,24 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
 #pragma unroll
         for (int j = 0; j < D; ++j) ld(j, j);
         int kt = 0;
+#ifndef FNN_WGRAD_PAIRED
+#define FNN_WGRAD_PAIRED 0      // measured with 1: the second launch 18.4 -> 20.4 us (the union launch's register budget); the strip kernel keeps it
+#endif
+        if constexpr (std::is_same<T, bs16_t>::value && FNN_WGRAD_PAIRED && (D % 2 == 0)) {
+            // bf16 pairs: two k-steps per product (mma_row2): three 16x16x32 MFMAs per tile and pair of k-steps instead of six 16x16x16
+            for (; kt + D <= nkt; kt += D) {
+#pragma unroll
+                for (int j = 0; j < D; j += 2) {
+                    mma_row2<4>(acc, ra[j], ra[j + 1], rb[j], rb[j + 1]);
+                    ld(j, kt + D + j); ld(j + 1, kt + D + j + 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < D; j += 2) {
+                if (kt + j + 1 < nkt) mma_row2<4>(acc, ra[j], ra[j + 1], rb[j], rb[j + 1]);
+                else if (kt + j < nkt) mma_row<4>(acc, ra[j], rb[j]);
+            }
+        } else {
         for (; kt + D <= nkt; kt += D) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -743,6 +787,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradProb& pr, const int b, con
 #pragma unroll
                 for (int n = 0; n < 4; ++n) mma(acc[n], ra[j], rb[j][n]);
             }
+        }
         }
     } else {
 #pragma unroll 4
@@ -832,6 +877,26 @@ template <typename T, int NK, int C, int D>
 __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r, const T* ap, const T* __restrict__ W, const int rt0, const int lane) {
     typedef typename Traits<T>::frag frag;
     constexpr int KS = Traits<T>::KS;
+#ifndef FNN_SPLIT_PAIRED
+#define FNN_SPLIT_PAIRED 1
+#endif
+    if constexpr (std::is_same<T, bs16_t>::value && FNN_SPLIT_PAIRED && D >= 2) {
+#pragma unroll
+        for (int kk = 0; kk + 1 < NK; kk += 2) {
+            const frag af0 = *reinterpret_cast<const frag*>(ap + kk * KS), af1 = *reinterpret_cast<const frag*>(ap + (kk + 1) * KS);
+            mma_row2<C>(acc, af0, af1, r.s[kk % D], r.s[(kk + 1) % D]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (kk + u + D < NK) {
+#pragma unroll
+                    for (int i = 0; i < C; ++i) r.s[(kk + u) % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + u + D, NK, lane));
+                }
+        }
+        if (NK & 1) {
+            const frag af = *reinterpret_cast<const frag*>(ap + (NK - 1) * KS);
+            mma_row<C>(acc, af, r.s[(NK - 1) % D]);
+        }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         const frag af = *reinterpret_cast<const frag*>(ap + kk * KS);
@@ -840,6 +905,7 @@ __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r
 #pragma unroll
             for (int i = 0; i < C; ++i) r.s[kk % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + D, NK, lane));
         }
+    }
     }
 }
 
