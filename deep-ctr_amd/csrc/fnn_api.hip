@@ -1114,10 +1114,24 @@ int fnn_set_shadowed(fnn_handle* h, const int32_t* tfr, int n, int memkind)
         HIPCHK(h, hipMalloc((void**)&h->shadow_dev, (size_t)cap * 3 * sizeof(int32_t)));
         h->shadow_cap = cap;
     }
-    if (n > 0)
+    if (n > 0) {
+        if (!h->table16) FAIL(h, FNN_ERR_STATE, "fnn_set_shadowed before fnn_set_table");
         HIPCHK(h, hipMemcpyAsync(h->shadow_dev, tfr, (size_t)n * 3 * sizeof(int32_t),
                                  memkind == FNN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
-    if (n > 0 && memkind == FNN_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->st));       // the caller's buffer may go away
+        // a row belongs to ONE field (fnn_set_table's field_of_row): the sparse-row update groups keys per field, so an entry that
+        // names a row under another field would put the row into two groups of one launch -- two unordered read-modify-writes.
+        // Checked here (a launch and a read of the flag; this call is rare), not left to show as a lost update one run in four.
+        hipLaunchKernelGGL(k_check_shadowed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->shadow_dev, n, h->field_of_row,
+                           h->n_rows, h->F, h->err_flag);
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipStreamSynchronize(h->st));                       // (also: the caller's host buffer may go away)
+        if (flag & 8) {
+            HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), h->st));
+            h->n_shadow = 0;
+            FAIL(h, FNN_ERR_ARG, "fnn_set_shadowed: an entry's row is outside the table or does not belong to the entry's field (field_of_row)");
+        }
+    }
     h->n_shadow = n;
     return FNN_OK;
 }

@@ -1439,6 +1439,16 @@ static __global__ void k_update(float* __restrict__ master, const float* __restr
     }
 }
 
+// fnn_set_shadowed: every (example, field, row) entry must name a row of that field (bit 3 of the flag otherwise)
+static __global__ void k_check_shadowed(const int32_t* __restrict__ tfr, int n, const int32_t* __restrict__ field_of_row, int64_t n_rows,
+                                        int F, int* __restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = tfr[3 * i + 1]; const int64_t r = tfr[3 * i + 2];
+    if (f < 0 || f >= F || r < 0 || r >= n_rows || field_of_row[r] != f) atomicOr(err, 8);
+}
+
 // ------------------------------------------------------------------------------------------
 // A6  sparse-row SGD with the reference's sequential duplicate semantics
 // (python/FNN_wnzh.py:299-306): a row hit by m examples (in example order) with slot gradients

@@ -140,7 +140,9 @@ int fnn_train_step(fnn_handle* h, const int32_t* ids, const float* y, int B,
  * ids [B, F] expresses; the reference's update loop nevertheless walks EVERY feature of the line (:300-306), so a shadowed
  * feature's row also takes `row * c - lr * gx[t][1 + field*K + l]`.  tfr [n][3] int32 = (example t in [0, B), field, row),
  * in any order; consumed by the next step (n = 0 clears).  FNN_MODE_FM; not combined with FNN_DP_SPARSE_EXCHANGE.  Such
- * steps take the layer-by-layer kernels (B + n <= 16384).  iPinYou lines hold one feature per field: n = 0 there. */
+ * steps take the layer-by-layer kernels (B + n <= 16384).  iPinYou lines hold one feature per field: n = 0 there.
+ * `field` must be the row's own field (fnn_set_table's field_of_row; FNN_ERR_ARG otherwise): the update groups keys per field, a
+ * row named under another field would sit in two groups of one launch.  Synchronises the handle's stream. */
 int fnn_set_shadowed(fnn_handle* h, const int32_t* tfr, int n, int memkind);
 
 /* Optional: hand the ids of an UPCOMING training batch to the library (DEVICE pointer, same

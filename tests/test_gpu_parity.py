@@ -920,7 +920,11 @@ def test_train_epoch_equals_the_step_loop(built):
     rng = np.random.RandomState(3)
     M1 = (rng.uniform(size=(11, H1)) < 0.5).astype(np.uint8)
     M2 = (rng.uniform(size=(11, H2)) < 0.5).astype(np.uint8)
-    sh = np.array([[5, 3, 7], [5, 9, 11], [250, 0, 2], [1029, 15, 900]], np.int32)      # (example, field, row), sorted by example
+    sh = np.array([[5, fo[7], 7], [5, fo[411], 411], [250, fo[2], 2], [1029, fo[900], 900]], np.int32)   # (example, field OF THE ROW, row), sorted by example
+    bad = make_engine(rows, fo, p)
+    with pytest.raises(FNNError, match='does not belong'):          # a row under another field would be updated by two groups at once
+        bad.set_shadowed(np.array([[5, (fo[7] + 1) % 16, 7]], np.int32))
+    bad.close()
     a, b = make_engine(rows, fo, p, lr=0.01, lam1=0.02), make_engine(rows, fo, p, lr=0.01, lam1=0.02)
     for j in range(11):                                            # 10 batches of 100 and one of 30
         lo, hi = j * 100, min(1030, (j + 1) * 100)
@@ -934,5 +938,8 @@ def test_train_epoch_equals_the_step_loop(built):
     b.train_epoch(ids_d, yf, 100, M1, M2, 0, 4, sh)                 # in two pieces, as FNN.py reads the dense state before the last batch
     b.train_epoch(ids_d, yf, 100, M1, M2, 4, None, sh)
     da, db = a.get_dense(), b.get_dense()
-    assert all(np.array_equal(da[k], db[k]) for k in da) and np.array_equal(a.get_table(), b.get_table())
+    bad = {k: float(np.abs(np.asarray(da[k], np.float64) - np.asarray(db[k], np.float64)).max()) for k in da if not np.array_equal(da[k], db[k])}
+    ta, tb = a.get_table(), b.get_table()
+    assert not bad and np.array_equal(ta, tb), "step loop vs train_epoch differ: dense %r, table rows %r" % (
+        bad, np.unique(np.argwhere(ta != tb)[:, 0])[:10].tolist())
     a.close(); b.close()
