@@ -22,7 +22,10 @@
  * e.g. torch.Tensor.data_ptr()) addresses.
  *
  * Layouts (row-major, contiguous): ids int32 [B, F] with slot f = field f and
- * -1 = no feature in that field; y float32 [B]; masks uint8 [H1], [H2];
+ * -1 = no feature in that field (FNN_MODE_FM: ids[t][f] must be a row of field f -- fnn_set_table's field_of_row --
+ * which DataFM / ctr_parse_examples guarantee; the sparse-row update groups keys per column without atomics, so one row
+ * under two columns of a batch is a data race there.  FNN_MODE_BAG detects such rows and adds atomically);
+ * y float32 [B]; masks uint8 [H1], [H2];
  * x / gx float32 [B, 1 + F*K] in the reference's layer-one layout
  * (x[0] = w_0, x[1 + f*K + l] = row(ids[f])[l],  python/FNN_wnzh.py:87-96).
  */
