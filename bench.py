@@ -382,7 +382,7 @@ def bench_fnn(args, precision, snn):
                     'avg_launch_ms': cand[dom],
                     # an event-bracketed slot = kernel + the event mechanism (a back-to-back pair alone: 'event_pair_ms');
                     # the kernel-only average of the committed rocprofv3 summary of this command is quoted beside it
-                    'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if (snn or precision != 'bf16') else rocprof_avg_ms(dom),
+                    'event_pair_ms': kern_ms.get('empty'), 'rocprof_avg_ms': None if snn else rocprof_avg_ms(dom, precision),
                     'algorithmic_per_example': per_ex,
                     'step': {'achieved': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9,
                              'frac': (39264 if snn else STEP_MIN_BYTES) * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -999,12 +999,16 @@ def pmc_traffic_ipnn(seg):
     return None
 
 
-def rocprof_avg_ms(kernel):
-    """Average duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/*_kernel_stats.csv), for comparison with the event-bracketed time measured live."""
+def rocprof_avg_ms(kernel, precision='bf16'):
+    """Average duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this command IN THIS
+    PRECISION (profiles/r*_fnn_<precision>_kernel_stats.csv; for bf16 also the older r*_kernel_stats.csv of the headline
+    command), for comparison with the event-bracketed time measured live."""
     import csv
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')) if 'ipnn' not in f)
+    allf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')))
+    files = [f for f in allf if os.path.basename(f).endswith('_fnn_%s_kernel_stats.csv' % precision)]
+    if not files and precision == 'bf16':
+        files = [f for f in allf if 'ipnn' not in f and '_fnn_' not in os.path.basename(f)]
     tag = {'step1': 'k_step1', 'step2': 'k_step2', 'step3': 'k_step3'}.get(kernel)
     if not files or not tag:
         return None
