@@ -399,15 +399,23 @@ def snn_train_step(p, ww0, bb0, ids, y, r1, r2, lr, lambda1, acti_type='tanh'):
     Mutates p, ww0, bb0 (bb0 must be an ndarray)."""
     x = snn_bag(ww0, bb0, ids)
     gx, pre, loss, p_drop, g = train_call(p, x, y, r1, r2, lr, lambda1, acti_type, reg_all=True)
+    snn_update(ww0, bb0, ids, x, gx, lr)
+    return {'x': x, 'gx': gx, 'loss': loss, 'p_drop': p_drop, 'grads': g, 'pre': pre}
+
+
+def snn_update(ww0, bb0, ids, x, gx, lr):
+    """The update loop of mytrain, python/SNN_RBM.py:285-291, per example in order:
+    bb0 = bb0 - lr*gx[t]*x[t]*(1-x[t]); ww0[f] = ww0[f] - lr*gx[t]*x[t]*(1-x[t]) for every active feature of the line (a
+    feature listed twice is visited twice).  ids [B,F], -1 = no feature.  In place (bb0 must be an ndarray).
+    Pinned by a run of the reference's own loop (tests/golden/ref_run.npz snn1 / snn2)."""
     B, F = ids.shape
     for t in range(B):
-        d = lr * gx[t] * x[t] * (1 - x[t])
-        bb0 -= d
+        bb0 -= lr * gx[t] * x[t] * (1 - x[t])
         for f in range(F):
             r = ids[t, f]
             if r >= 0:
-                ww0[r] = ww0[r] - d
-    return {'x': x, 'gx': gx, 'loss': loss, 'p_drop': p_drop, 'grads': g, 'pre': pre}
+                ww0[r] = ww0[r] - lr * gx[t] * x[t] * (1 - x[t])
+    return ww0, bb0
 
 
 def snn_predict(p, ww0, bb0, ids, acti_type='tanh'):

@@ -140,3 +140,127 @@ def test_rbm_oracle_equals_reference_get_rbm_weights(ref, tag):
         want = ref['rbm_%s_res%d' % (tag, i)]
         assert r.shape == want.shape
         np.testing.assert_allclose(r, want, rtol=0, atol=1e-12 * max(1.0, np.abs(want).max()), err_msg='result %d' % i)
+
+
+# =================================================================================================================
+# Round 3: the plain-Python halves of the Theano / TensorFlow scripts (statements of FNN_wnzh.py, SNN_RBM.py and
+# baseline.py executed node by node; make_golden_ref.py part 2).  This pins A6, the update of A8 and the host side of N4.
+def fnn_problem(ref, tag):
+    """The inputs of an `upd*` fixture as the oracle wants them, and the dense parameters its gx was made with."""
+    feats = [int(f) for f in ref['fnn_script_feats']]
+    row_of = {f: i for i, f in enumerate(feats)}
+    field_of = {f: int(v) for f, v in zip(feats, ref['fnn_script_fields'])}
+    lists = [unpad(r) for r in ref[tag + '_feats']]
+    lr, lam = (float(v) for v in ref[tag + '_lr_lambda'])
+    return feats, row_of, field_of, lists, lr, lam
+
+
+def fnn_dense(ref, tag, xdim=177):
+    seed = int(ref[tag + '_seed'])
+    p = orc.init_fnn_weights(xdim, 300, 100)
+    p['w3'] = np.random.RandomState(seed).uniform(-0.1, 0.1, 100)
+    r1 = (np.random.RandomState(seed + 1).uniform(size=300) < 0.5).astype(np.float64)
+    r2 = (np.random.RandomState(seed + 2).uniform(size=100) < 0.5).astype(np.float64)
+    return p, r1, r2
+
+
+def test_script_statements_parse_the_model_like_DataFM(ref):
+    """FNN_wnzh.py:62-88 (the script's own copy of the model parser and index helper) == data_fm.DataFM == the oracle."""
+    assert np.array_equal(ref['fnn_script_feats'], ref['fm_feats']) and np.array_equal(ref['fnn_script_weights'], ref['fm_weights'])
+    assert np.array_equal(ref['fnn_script_fields'], ref['fm_fields'])
+    assert [float(v) for v in ref['fnn_script_w0_k_xdim']] == [float(ref['fm_w0']), float(ref['fm_k']), float(ref['fm_xdim'])]
+    w0, k, xdim, fw, ff = orc.parse_fm_model(os.path.join(DEMO, 'fm.model.txt'))
+    f0 = int(ref['fnn_script_feats'][0])
+    assert 1 + ff[f0] * k + 3 == int(ref['fnn_script_index_7_3'])
+
+
+@pytest.mark.parametrize("tag", ['upd1', 'upd2', 'upd3'])
+def test_sparse_row_update_equals_reference_loop(ref, tag, built):
+    """A6: the reference's `for t in range(b_size): for feat in ft: for l in range(k)` statement (FNN_wnzh.py:299-306), run on
+    these lines and this gx, against every restatement of it: the loop over feature lists (bit for bit: same operations in
+    the same order), the id-matrix form and its closed form `row c^m - lr sum_j g_j c^(m-j)` (what the HIP kernels compute),
+    and the vectorised CPU baseline of bench.py.  upd2: duplicate-heavy, lr 0.05, lambda_fm 0.3, a blank line in
+    the file; upd3: two features of one field on a line, a feature listed twice."""
+    feats, row_of, field_of, lists, lr, lam = fnn_problem(ref, tag)
+    w0, k, xdim, fw, ff = orc.parse_fm_model(os.path.join(DEMO, 'fm.model.txt'))
+    before, after, gx = ref['fnn_script_weights'], ref[tag + '_after'], ref[tag + '_gx']
+    # the script's get_batch_data loop + get_fxy on the same file: lines -> feature lists, x, y
+    lines = [str(v) for v in ref[tag + '_lines'] if str(v).strip()]
+    assert [orc.parse_line(ln)[0] for ln in lines] == lists and [orc.parse_line(ln)[1] for ln in lines] == [int(v) for v in ref[tag + '_y']]
+    x = np.array([orc.feats_to_layer_one_array(f, w0, k, xdim, fw, ff) for f in lists])
+    assert np.array_equal(x, ref[tag + '_x'])
+    rows = before.copy()
+    orc.scatter_sgd_feats(rows, lists, row_of, field_of, gx, lr, lam)
+    assert np.array_equal(rows, after)
+    n_changed = int((np.abs(after - before).max(axis=1) > 0).sum())
+    assert n_changed == len({f for ft in lists for f in ft})                    # exactly the listed features' rows moved
+    one_per_field = all(len({field_of[f] for f in ft}) == len(ft) for ft in lists)
+    assert one_per_field == (tag != 'upd3')
+    if one_per_field:
+        ids = np.full((len(lists), 16), -1, np.int64)
+        for t, ft in enumerate(lists):
+            for f in ft:
+                ids[t, field_of[f]] = row_of[f]
+        assert np.array_equal(orc.scatter_sgd(before.copy(), ids, gx, lr, lam), after)
+        tol = 1e-12 * np.abs(after).max()
+        assert np.abs(orc.scatter_sgd_closed_form(before, ids, gx, lr, lam) - after).max() <= tol
+        assert np.abs(orc.scatter_sgd_vec(before.copy(), ids, gx, lr, lam) - after).max() <= tol
+    if tag != 'upd2':
+        # the fixture's gx is the oracle's train_call on the reference's x (the dense parameters are re-made from the seed):
+        # what the GPU tests rebuild to run the same step on the device
+        p, r1, r2 = fnn_dense(ref, tag)
+        gx2 = orc.train_call(p, x, ref[tag + '_y'].astype(np.float64), r1, r2, lr, 0.0)[0]
+        assert np.array_equal(gx2, gx)
+
+
+@pytest.mark.parametrize("tag", ['snn1', 'snn2'])
+def test_snn_bag_and_update_equal_reference_loops(ref, tag, tmp_path, built):
+    """A8: the line loop of get_fi_h1_y (SNN_RBM.py:242-256: a token counts when its value is 1; x = sigmoid(sum of the
+    active rows + bb0)) and the update loop of mytrain (:285-291), run by the reference's statements, against the oracle and
+    the native reader.  snn2: values 0 / 2, features listed twice, random gx, lr 0.05."""
+    s0, s1, x_dim, h0 = (int(v) for v in ref[tag + '_seeds_shape'])
+    ww0 = np.random.RandomState(s0).uniform(-0.1, 0.1, (x_dim, h0))
+    bb0 = np.random.RandomState(s1).uniform(-0.1, 0.1, h0)
+    active = [unpad(r) for r in ref[tag + '_active']]
+    lines = [str(v) for v in ref[tag + '_lines']]
+    path = tmp_path / 'snn.fm.txt'
+    path.write_text('\n'.join(lines) + '\n')
+    ids_o, y_o = io.snn_active(str(path))                                       # the Python restatement of the reader
+    assert [unpad(r) for r in ids_o] == active and np.array_equal(y_o, ref[tag + '_y'])
+    ids_n, _, y_n = ingest.parse_examples(str(path), ingest.MODE_SNN_ACTIVE, None, 16)
+    assert [unpad(r) for r in ids_n] == active and np.array_equal(y_n, ref[tag + '_y'])
+    ids = np.array([a + [-1] * (16 - len(a)) for a in active], np.int64)
+    x = orc.snn_bag(ww0, bb0, ids)
+    np.testing.assert_allclose(x, ref[tag + '_x'], rtol=0, atol=1e-15)
+    w, b = ww0.copy(), bb0.copy()
+    orc.snn_update(w, b, ids, ref[tag + '_x'], ref[tag + '_gx'], float(ref[tag + '_lr']))
+    touched = ref[tag + '_touched']
+    assert np.array_equal(touched, np.unique(ids[ids >= 0]))
+    assert np.abs(w[touched] - ref[tag + '_ww0_after_touched']).max() <= 1e-15 and np.abs(b - ref[tag + '_bb0_after']).max() <= 1e-15
+    rest = np.setdiff1d(np.arange(x_dim), touched)
+    assert np.array_equal(w[rest], ww0[rest])
+
+
+def test_early_stop_and_recalibration_equal_reference(ref, capsys):
+    """Row N4, host side: deep-ctr_amd/baseline.py (its own formulation: two window means) makes the decision of the
+    reference's early_stop (baseline.py:262-281) for every prefix of six metric series under six window settings, both
+    metrics (4,608 calls); the re-calibration equals both statements of the driver (:369, :422) to the bit."""
+    from deep_ctr_amd import baseline as bl
+    assert [float(v) for v in ref['baseline_defaults']] == [0.025, 1.0, 10.0, 10.0]
+    assert bl.nds_rate == float(ref['baseline_defaults'][0])
+    for i in (0, 1):
+        assert np.array_equal(bl.re_calibrate(ref['nds_in']), ref['nds_out%d' % i])
+    saved = (bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window)
+    try:
+        stops = 0
+        for ci, cfg in enumerate(ref['es_cfgs']):
+            bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = (int(v) for v in cfg)
+            for si, s in enumerate(ref['es_series']):
+                for mi, metric in enumerate(('auc', 'rmse')):
+                    got = [bl.early_stop(n, [float(v) for v in s[:n]], metric) for n in range(1, len(s) + 1)]
+                    assert got == [bool(v) for v in ref['es_result'][ci, si, mi]], (ci, si, metric)
+                    stops += sum(got)
+        assert stops > 1000 and not ref['es_result'][:, 4].any()             # a flat metric never stops
+    finally:
+        bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = saved
+    assert 'early stop at step' in capsys.readouterr().out
