@@ -101,6 +101,12 @@ def main():
                          "(SURVEY 8d config 4, '4096 split 8-way')")
     ap.add_argument('--dp-sparse', default='local', choices=['local', 'exchange'],
                     help='N > 1: local = every rank applies its own shard\'s row updates (north_star); exchange = the exact mode')
+    ap.add_argument('--dp-collective', default='rccl', choices=['rccl', 'p2p'],
+                    help='N > 1: who performs the dense all-reduce of the step -- RCCL on the library stream, or the one-shot '
+                         'peer-pointer all-reduce inside the update launch (hipIpc-mapped exchange regions)')
+    ap.add_argument('--dp-payload', default=None, choices=['slabs', 'bucket'],
+                    help='N > 1, --dp-collective rccl: what the all-reduce carries -- the split-K slabs (2 MB, three launches; the '
+                         'default, or $FNN_DP_PAYLOAD) or the flat bucket (0.5 MB, four launches); p2p always carries the bucket')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -288,7 +294,7 @@ def bench_fnn(args, precision, snn):
     if dist is not None:
         from deep_ctr_amd.dp import DataParallelFNN
         try:
-            dpw = DataParallelFNN(eng, sparse=args.dp_sparse if not snn else 'local')
+            dpw = DataParallelFNN(eng, sparse=args.dp_sparse if not snn else 'local', payload=args.dp_payload, collective=args.dp_collective)
             collective = dpw.collective
         except Exception as e:
             dp_error = '%s: %s' % (type(e).__name__, e)
@@ -358,7 +364,7 @@ def bench_fnn(args, precision, snn):
             step(i)
     sync_all()
     if rank == 0:
-        for name in ('empty', 'step1', 'step2', 'allreduce', 'allgather', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse',
+        for name in ('empty', 'step1', 'step2', 'allreduce', 'p2p_update', 'update', 'allgather', 'step3', 'step2_dense', 'step2_sparse', 'step3_dense', 'step3_sparse',
                      'sort_global', 'scatter_global', 'sort_now', 'mlp', 'gather', 'fwd1', 'fwd2', 'head', 'bwd1', 'gx', 'wgrad', 'reduce', 'update', 'sort',
                      'scatter', 'finalize'):
             kern_ms[name] = eng.prof_get(name)[0]
@@ -450,8 +456,19 @@ def bench_fnn(args, precision, snn):
             'roofline': roofline, 'cpu_baseline': cpu, 'cpu_baseline_vectorised': cpu_vec, 'kernel_ms': kern_ms,
         }
         if dist is not None:
+            cfg = eng.dp_config() if not split else {'payload': 'bucket', 'collective': 'torch.distributed', 'region': 'none'}
+            p2p = cfg['collective'] == 'p2p'
+            ev = kern_ms.get('empty') or 0.0
             out['data_parallel'] = {'collective': collective, 'sparse_rows': args.dp_sparse if not snn else 'local',
-                                    'launches_per_step': 'three + one all-reduce of the split-K weight-gradient slabs' if not split else 'five + all-reduce of the flat bucket',
+                                    'payload': cfg['payload'], 'exchange_region': cfg['region'],
+                                    # event-bracketed slot of the collective on rank 0, the event pair's own cost taken off; for p2p the
+                                    # slot is the update launch that performs the all-reduce (wait for the peers + sum + update)
+                                    'collective_us': max(0.0, ((kern_ms.get('p2p_update') if p2p else kern_ms.get('allreduce')) or 0.0) - ev) * 1e3,
+                                    'collective_slot': 'p2p_update (all-reduce + dense update in one launch)' if p2p else 'allreduce',
+                                    'launches_per_step': ('five + all-reduce of the flat bucket' if split else
+                                                          'three + the p2p update launch (sums every rank\'s bucket over peer pointers)' if p2p else
+                                                          'three + all-reduce of the flat bucket + update launch' if cfg['payload'] == 'bucket' else
+                                                          'three + one all-reduce of the split-K weight-gradient slabs'),
                                     'native_setup_error': dp_error, 'exact_mode_check': dp_check,
                                     'rehearsal_all_ranks_on_one_gpu': rehearse}
     eng.close()

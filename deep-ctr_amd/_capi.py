@@ -20,6 +20,8 @@ FNN_ACT_TANH, FNN_ACT_SIGMOID, FNN_ACT_LINEAR = 0, 1, 2
 FNN_MEM_HOST, FNN_MEM_DEVICE = 0, 1
 FNN_MODE_FM, FNN_MODE_BAG = 0, 1
 FNN_DP_SPARSE_LOCAL, FNN_DP_SPARSE_EXCHANGE = 0, 1
+FNN_DP_PAYLOAD_SLABS, FNN_DP_PAYLOAD_BUCKET = 0, 1
+FNN_DP_COLLECTIVE_CALLBACK, FNN_DP_COLLECTIVE_P2P = 0, 1
 # collective callbacks of fnn_dp_init_custom: (ctx, buf, n_floats, stream) / (ctx, send, recv, bytes_per_rank, stream) -> 0 = OK
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -60,6 +62,11 @@ SIGNATURES = {
     "fnn_dp_init": (_i, [_vp, _i, _i, _vp, _i]),
     "fnn_dp_init_custom": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i]),
     "fnn_dp_shutdown": (_i, [_vp]),
+    "fnn_dp_set_payload": (_i, [_vp, _i]),
+    "fnn_dp_p2p_export": (_i, [_vp, _vp, _i]),
+    "fnn_dp_p2p_attach": (_i, [_vp, _vp, _i]),
+    "fnn_dp_set_collective": (_i, [_vp, _i]),
+    "fnn_dp_get_config": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "fnn_step_scatter": (_i, [_vp]),

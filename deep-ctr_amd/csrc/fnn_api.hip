@@ -97,6 +97,12 @@ struct fnn_handle {
     SortSlot gsl; int gN2 = 0; void* gws = nullptr; size_t gws_bytes = 0;      // grouping of a GLOBAL batch (fnn_step_scatter_global), grown on demand
     int cpow_cap = 0;                   // entries allocated in cpow_dev
     bool step_native_dp = false;        // the step in flight runs its own collective (fnn_train_step after fnn_dp_init)
+    // what the dense collective carries and who performs it (fnn_dp_set_payload / fnn_dp_set_collective): handle-wide, never per shard
+    int dp_payload = FNN_DP_PAYLOAD_SLABS, dp_collective = FNN_DP_COLLECTIVE_CALLBACK;
+    // one-shot all-reduce over peer pointers: this rank's exchange region = [2 parities][xr_nbp floats] buckets, then 8 flags of 64 B
+    float* xr = nullptr; size_t xr_nbp = 0, xr_bytes = 0; int xr_kind = 0; bool xr_same_process = false;
+    float* peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool peer_opened[8] = {false, false, false, false, false, false, false, false};
+    bool p2p_attached = false; unsigned long long dp_step_no = 0;
     int step_bsize = 0;                 // its b_size (the decay table is rebuilt with it when a global batch outgrows the table)
     // profiling
     bool prof = false;
@@ -145,6 +151,7 @@ int check_async(fnn_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->st));
     if (flag) {
         HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), h->st));
+        if (flag & 16) FAIL(h, FNN_ERR_HIP, "data-parallel p2p all-reduce: a peer's flag did not arrive in time; the dense tensors of that step were left untouched");
         FAIL(h, FNN_ERR_RANGE, "feature id outside [-1, n_rows) (reference: KeyError, python/FNN_wnzh.py:95)");
     }
     return FNN_OK;
@@ -290,7 +297,7 @@ void launch_step2(fnn_handle* h, bool dense, bool sparse)
 }
 
 template <typename T>
-void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update)
+void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update, float* bucket_dst = nullptr)
 {
     const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
     const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
@@ -301,7 +308,7 @@ void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update)
         ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
         const int nred = dense ? (int)((h->nw12 / 4 + 255) / 256) + (int)((h->nw - h->nw12 + h->nbag + 255) / 256) + 1 : 0;
         TailArgs ta{h->slab, h->splitk, h->nw, h->nw12, h->nslab, h->master, h->cfg.lambda1, h->cfg.reg_all,
-                    h->loss_t, Ba, h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
+                    h->loss_t, Ba, bucket_dst ? bucket_dst : h->bucket, h->loss_dev, h->cfg.lr, h->K1p, h->H1p, h->H2p,
                     h->w1, h->w1t, h->w2, h->w2t, nred, h->bb0, h->nbag, h->off_bag};
         const int stamp = have_next ? next_stamp(h, h->slot[nxt]) : 0;      // the rank merge of the NEXT batch marks its shared rows
         SortArgs so{h->next_ids, h->next_B, h->F, h->n_rows, h->slot[nxt].rec, h->slot[nxt].owner_cnt,
@@ -337,10 +344,40 @@ void launch_steps23(fnn_handle* h, bool dense, bool sparse, bool update)
 int dp_allreduce(fnn_handle* h, float* buf, size_t n, const char* what)
 {
     ProfScope ps(h, "allreduce", h->st);
+    h->err.clear();                              // the RCCL callback leaves its message here; a caller's callback leaves nothing
     const int rc = h->dp_allreduce(h->dp_ctx, buf, (int64_t)n, (void*)h->st);
-    if (rc != 0) FAIL(h, FNN_ERR_HIP, std::string("data-parallel all-reduce (") + what + ") failed: " + h->err);
+    if (rc != 0) FAIL(h, FNN_ERR_HIP, std::string("data-parallel all-reduce (") + what + ") failed" + (h->err.empty() ? std::string(": the callback returned ") + std::to_string(rc) : ": " + h->err));
     return FNN_OK;
 }
+
+// Bucket payload: the flat bucket holds THIS rank's dense gradients (launch 3 without its update, or the layer-by-layer
+// k_reduce); sum it over the ranks and apply theta <- theta - lr * (sum + L2 term).  Callback collective: all-reduce in place,
+// then k_update.  P2P: the bucket sits in (or is copied into) this rank's exchange region and ONE launch does the rest.
+inline float* p2p_bucket(fnn_handle* h) { return h->xr + (size_t)(h->dp_step_no & 1) * h->xr_nbp; }
+template <typename T> int dp_finish_bucket(fnn_handle* h, bool in_region)
+{
+    if (h->dp_collective == FNN_DP_COLLECTIVE_P2P) {
+        if (!in_region)
+            HIPCHK(h, hipMemcpyAsync(p2p_bucket(h), h->bucket, (h->nw + h->nbag) * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+        ProfScope ps(h, "p2p_update", h->st);
+        P2PArgs pa;
+        for (int r = 0; r < 8; ++r) pa.peer[r] = h->peer[r];
+        pa.world = h->dp_world; pa.rank = h->dp_rank; pa.step = h->dp_step_no + 1;
+        pa.bucket_off = (size_t)(h->dp_step_no & 1) * h->xr_nbp; pa.flag_off = 2 * h->xr_nbp * sizeof(float); pa.err = h->err_flag;
+        const size_t n = h->nw + h->nbag;
+        hipLaunchKernelGGL((k_p2p_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, pa, h->master, h->cfg.lr,
+                           h->cfg.lambda1, h->cfg.reg_all, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t,
+                           h->bb0, h->nw, h->nbag);
+        h->dp_step_no++;
+        return FNN_OK;
+    }
+    int rc = dp_allreduce(h, h->bucket, h->nw + h->nbag, "dense-gradient bucket");
+    if (rc != FNN_OK) return rc;
+    ProfScope ps(h, "update", h->st);
+    launch_update<T>(h, h->bucket, h->cfg.lr);
+    return FNN_OK;
+}
+inline bool dp_bucket_mode(const fnn_handle* h) { return h->dp_collective == FNN_DP_COLLECTIVE_P2P || h->dp_payload == FNN_DP_PAYLOAD_BUCKET; }
 
 int ensure_global_ws(fnn_handle* h, int B_g);
 int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g);
@@ -399,9 +436,19 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
         // slabs of the weight gradients are all-reduced in place, the third launch then sums GLOBAL slabs
         const bool local = h->dp_sparse == FNN_DP_SPARSE_LOCAL;
         launch_step2<T>(h, true, local);
-        int rc = dp_allreduce(h, h->slab, (size_t)h->splitk * h->nslab, "weight-gradient slabs");
-        if (rc != FNN_OK) return rc;
-        launch_step3<T>(h, true, local, true);
+        int rc;
+        if (!dp_bucket_mode(h)) {
+            rc = dp_allreduce(h, h->slab, (size_t)h->splitk * h->nslab, "weight-gradient slabs");
+            if (rc != FNN_OK) return rc;
+            launch_step3<T>(h, true, local, true);
+        } else {
+            // bucket payload: launch 3 sums this rank's slabs (no update), the collective carries a quarter of the bytes, a fourth
+            // launch applies the update -- with the p2p collective that launch IS the all-reduce
+            const bool p2p = h->dp_collective == FNN_DP_COLLECTIVE_P2P;
+            launch_step3<T>(h, true, local, false, p2p ? p2p_bucket(h) : nullptr);
+            rc = dp_finish_bucket<T>(h, p2p);
+            if (rc != FNN_OK) return rc;
+        }
         if (!local) {
             h->pend_have_next = false;
             rc = dp_exchange_sparse(h, ids, B);
@@ -494,6 +541,12 @@ int run_step(fnn_handle* h, const int32_t* ids, const float* y, int B, const uin
         const WgradArgs wa = make_wgrad_args<T>(h, Ba);
         hipLaunchKernelGGL((k_wgrad<T>), dim3(wgrad_blocks(wa), h->splitk), dim3(256), 0, h->st, wa);
     }
+    if (train && h->step_native_dp && !dp_bucket_mode(h)) {
+        // native data parallelism, slabs payload: the SAME collective as the three-launch path issues, so that a rank whose shard
+        // takes these kernels (shadowed features, B > 4096) pairs with peers that do not (round-2 advisor: mismatched counts)
+        int rc = dp_allreduce(h, h->slab, (size_t)h->splitk * h->nslab, "weight-gradient slabs");
+        if (rc != FNN_OK) return rc;
+    }
     {
         ProfScope ps(h, "reduce", h->st);
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((h->nw + 255) / 256 + 1)), dim3(256), 0, h->st, h->slab,
@@ -547,9 +600,7 @@ int ensure_global_ws(fnn_handle* h, int B_g)
         if (h->step_bsize > 0 && (rc = update_cpow(h, h->step_bsize, B_g)) != FNN_OK) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->st));
-    if (N2 == 16384) HIPCHK(h, hipFuncSetAttribute((const void*)k_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, N2 * 8));
-    else if (N2 == 8192) HIPCHK(h, hipFuncSetAttribute((const void*)k_sort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, N2 * 8));
-    return FNN_OK;
+    return FNN_OK;                              // (the LDS attributes of k_sort<8> / <16> are set at fnn_create)
 }
 
 // sparse-row SGD of a global batch in global example order (python/FNN_wnzh.py:299-306): one grouping per field over the
@@ -635,6 +686,17 @@ int rccl_allgather_cb(void* ctx, const void* send, void* recv, int64_t bytes, vo
     return 0;
 }
 
+void p2p_release(fnn_handle* h)
+{
+    for (int r = 0; r < 8; ++r) {
+        if (h->peer_opened[r] && h->peer[r]) hipIpcCloseMemHandle(h->peer[r]);
+        h->peer[r] = nullptr; h->peer_opened[r] = false;
+    }
+    if (h->xr) hipFree(h->xr);
+    h->xr = nullptr; h->xr_kind = 0; h->p2p_attached = false; h->dp_step_no = 0;
+    if (h->dp_collective == FNN_DP_COLLECTIVE_P2P) h->dp_collective = FNN_DP_COLLECTIVE_CALLBACK;
+}
+
 int dp_setup(fnn_handle* h, int rank, int world, int sparse_mode)
 {
     if (world < 1 || rank < 0 || rank >= world) FAIL(h, FNN_ERR_ARG, "fnn_dp_init: rank / world out of range");
@@ -655,6 +717,11 @@ int dp_setup(fnn_handle* h, int rank, int world, int sparse_mode)
     }
     h->dp_rank = rank; h->dp_world = world; h->dp_sparse = sparse_mode;
     h->sorted_ids = nullptr; h->next_ids = nullptr;
+    h->dp_payload = FNN_DP_PAYLOAD_SLABS; h->dp_collective = FNN_DP_COLLECTIVE_CALLBACK;
+    if (const char* ev = getenv("FNN_DP_PAYLOAD")) {
+        if (!strcmp(ev, "bucket")) h->dp_payload = FNN_DP_PAYLOAD_BUCKET;
+        else if (strcmp(ev, "slabs") != 0) FAIL(h, FNN_ERR_ARG, "FNN_DP_PAYLOAD must be slabs or bucket");
+    }
     return FNN_OK;
 }
 
@@ -776,10 +843,16 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     CK(alloc_dev(h, &h->st_m1, (size_t)h->H1p)); CK(alloc_dev(h, &h->st_m2, (size_t)h->H2p));
     CK(alloc_dev(h, &h->st_p, (size_t)h->Bmax));
     CK(alloc_dev(h, &h->st_x, (size_t)h->Bmax * h->xdim));
-    if (h->N2max == 8192)
-        HK(hipFuncSetAttribute((const void*)k_sort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
-    if (h->N2max == 16384)
-        HK(hipFuncSetAttribute((const void*)k_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->N2max * 8));
+    // dynamic LDS beyond the 64 KB default, set once and for every size a later call can ask for (round-2 advisor: the workspace
+    // of a global batch grows monotonically, so a smaller batch after a larger one used to launch k_sort<8> without its attribute;
+    // with the kernel's static counter k_sort<8> at 8192 keys is 65,540 bytes)
+    HK(hipFuncSetAttribute((const void*)k_sort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+    HK(hipFuncSetAttribute((const void*)k_sort<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    if (!h->bag) {
+        const size_t gl = (size_t)GR_EX * (h->xdim + h->F) * sizeof(float);          // 65,600 bytes at F = 64, K = 15
+        if (gl > 160 * 1024) { h->err = "n_fields * k too large for the reference-layout gather tile"; return fail(FNN_ERR_ARG); }
+        HK(hipFuncSetAttribute((const void*)k_gather_ref, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(gl, (size_t)65536)));
+    }
     HK(hipStreamSynchronize(h->st));
 #undef CK
 #undef HK
@@ -793,6 +866,7 @@ int fnn_destroy(fnn_handle* h)
     hipSetDevice(h->dev);
     if (h->st) hipStreamSynchronize(h->st);
     if (h->comm && h->dp_own_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    p2p_release(h);
     for (void* q : {(void*)h->tag_first, (void*)h->slot[0].tag_shared, (void*)h->slot[1].tag_shared, (void*)h->shadow_dev, (void*)h->xg_ids_send, (void*)h->xg_ids, (void*)h->xg_gxp, (void*)h->gsl.rec, (void*)h->gsl.part, (void*)h->gsl.owners,
                     (void*)h->gsl.owner_cnt, h->gws}) if (q) hipFree(q);
     for (auto& kv : h->prof_slots) for (auto& p : kv.second.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -1198,6 +1272,90 @@ int fnn_dp_shutdown(fnn_handle* h)
     h->comm = nullptr; h->dp_own_comm = false;
     h->dp = false; h->dp_allreduce = nullptr; h->dp_allgather = nullptr; h->dp_ctx = nullptr;
     h->dp_rank = 0; h->dp_world = 1; h->dp_sparse = FNN_DP_SPARSE_LOCAL;
+    p2p_release(h);
+    h->dp_payload = FNN_DP_PAYLOAD_SLABS; h->dp_collective = FNN_DP_COLLECTIVE_CALLBACK;
+    return FNN_OK;
+}
+
+int fnn_dp_set_payload(fnn_handle* h, int payload)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (payload != FNN_DP_PAYLOAD_SLABS && payload != FNN_DP_PAYLOAD_BUCKET) FAIL(h, FNN_ERR_ARG, "fnn_dp_set_payload: bad payload");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_set_payload inside a step");
+    h->dp_payload = payload;
+    return FNN_OK;
+}
+
+int fnn_dp_p2p_export(fnn_handle* h, void* handle64_out, int same_process)
+{
+    if (!h || !handle64_out) return FNN_ERR_ARG;
+    if (!h->dp) FAIL(h, FNN_ERR_STATE, "fnn_dp_p2p_export before fnn_dp_init / fnn_dp_init_custom");
+    if (h->dp_world > 8) FAIL(h, FNN_ERR_ARG, "the p2p all-reduce serves up to 8 ranks (one node)");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_p2p_export inside a step");
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    p2p_release(h);
+    h->xr_nbp = (size_t)rup((int)(h->nw + h->nbag), 64);
+    h->xr_bytes = 2 * h->xr_nbp * sizeof(float) + 8 * 64;
+    // memory that stays coherent between devices: uncached, else fine-grained ($FNN_P2P_REGION = uncached | finegrained | plain
+    // picks one; plain hipMalloc only where the ranks share a process and a device)
+    const char* want = getenv("FNN_P2P_REGION");
+    void* q = nullptr; h->xr_kind = 0;
+    if ((!want || !strcmp(want, "uncached")) && hipExtMallocWithFlags(&q, h->xr_bytes, hipDeviceMallocUncached) == hipSuccess) h->xr_kind = 1;
+    else if ((!want || !strcmp(want, "finegrained")) && hipExtMallocWithFlags(&q, h->xr_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xr_kind = 2;
+    else if (((!want && same_process) || (want && !strcmp(want, "plain"))) && hipMalloc(&q, h->xr_bytes) == hipSuccess) h->xr_kind = 3;
+    (void)hipGetLastError();
+    if (!h->xr_kind) FAIL(h, FNN_ERR_NOMEM, "fnn_dp_p2p_export: no uncached / fine-grained device memory for the exchange region");
+    h->xr = static_cast<float*>(q);
+    HIPCHK(h, hipMemset(h->xr, 0, h->xr_bytes));
+    h->xr_same_process = same_process != 0;
+    memset(handle64_out, 0, 64);
+    if (same_process) memcpy(handle64_out, &h->xr, sizeof(void*));
+    else {
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+        hipIpcMemHandle_t mh;
+        HIPCHK(h, hipIpcGetMemHandle(&mh, h->xr));
+        memcpy(handle64_out, &mh, 64);
+    }
+    return FNN_OK;
+}
+
+int fnn_dp_p2p_attach(fnn_handle* h, const void* handles, int same_process)
+{
+    if (!h || !handles) return FNN_ERR_ARG;
+    if (!h->dp || !h->xr) FAIL(h, FNN_ERR_STATE, "fnn_dp_p2p_attach before fnn_dp_p2p_export");
+    if ((same_process != 0) != h->xr_same_process) FAIL(h, FNN_ERR_ARG, "fnn_dp_p2p_attach: same_process differs from fnn_dp_p2p_export");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const char* hs = static_cast<const char*>(handles);
+    for (int r = 0; r < h->dp_world; ++r) {
+        if (r == h->dp_rank) { h->peer[r] = h->xr; continue; }
+        if (same_process) { void* q; memcpy(&q, hs + 64 * r, sizeof(void*)); h->peer[r] = static_cast<float*>(q); continue; }
+        hipIpcMemHandle_t mh; memcpy(&mh, hs + 64 * r, 64);
+        void* q = nullptr;
+        HIPCHK(h, hipIpcOpenMemHandle(&q, mh, hipIpcMemLazyEnablePeerAccess));
+        h->peer[r] = static_cast<float*>(q); h->peer_opened[r] = true;
+    }
+    for (int r = 0; r < h->dp_world; ++r) if (!h->peer[r]) FAIL(h, FNN_ERR_ARG, "fnn_dp_p2p_attach: a null region");
+    h->p2p_attached = true; h->dp_step_no = 0;
+    return FNN_OK;
+}
+
+int fnn_dp_set_collective(fnn_handle* h, int collective)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (collective != FNN_DP_COLLECTIVE_CALLBACK && collective != FNN_DP_COLLECTIVE_P2P) FAIL(h, FNN_ERR_ARG, "fnn_dp_set_collective: bad collective");
+    if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_set_collective inside a step");
+    if (collective == FNN_DP_COLLECTIVE_P2P && !(h->dp && h->p2p_attached)) FAIL(h, FNN_ERR_STATE, "FNN_DP_COLLECTIVE_P2P needs fnn_dp_p2p_export + fnn_dp_p2p_attach on every rank first");
+    h->dp_collective = collective;
+    return FNN_OK;
+}
+
+int fnn_dp_get_config(fnn_handle* h, int* payload, int* collective, int* region_kind)
+{
+    if (!h) return FNN_ERR_ARG;
+    if (payload) *payload = dp_bucket_mode(h) ? FNN_DP_PAYLOAD_BUCKET : FNN_DP_PAYLOAD_SLABS;
+    if (collective) *collective = h->dp_collective;
+    if (region_kind) *region_kind = h->xr_kind;
     return FNN_OK;
 }
 
@@ -1250,12 +1408,13 @@ int fnn_step_end(fnn_handle* h, float* loss_sum_out)
     HIPCHK(h, hipSetDevice(h->dev));
     if (h->scatter_pending) { int rc = fnn_step_scatter(h); if (rc != FNN_OK) return rc; }
     if (h->update_pending) {
-        if (h->step_native_dp) {        // layer-by-layer path under native data parallelism: the flat bucket is what is summed
-            int rc = dp_allreduce(h, h->bucket, h->nw + h->nbag, "dense-gradient bucket");
-            if (rc != FNN_OK) return rc;
+        if (h->step_native_dp && dp_bucket_mode(h)) {     // layer-by-layer path under native data parallelism, bucket payload
+            int rc = BY_PREC_RC(h, dp_finish_bucket, (h, false));
+            if (rc != FNN_OK) { h->in_step = false; return rc; }
+        } else {                                           // (slabs payload: k_reduce already summed GLOBAL slabs)
+            ProfScope ps(h, "update", h->st);
+            BY_PREC(h, launch_update, (h, h->bucket, h->cfg.lr));
         }
-        ProfScope ps(h, "update", h->st);
-        BY_PREC(h, launch_update, (h, h->bucket, h->cfg.lr));
     }
     HIPCHK(h, hipGetLastError());
     h->in_step = false;

@@ -305,4 +305,66 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data parallelism, FNN_DP_COLLECTIVE_P2P: the update launch that IS the all-reduce.  Every rank's exchange region
+// ([2 parities][nbp floats] buckets, then 8 flags on 64-byte lines of their own) is mapped by every peer (hipIpc*).
+//   1. block 0, lane p: release at system scope (this rank's bucket of the step -- written by the launch before this one -- is
+//      visible to every device), then store the step number into flag[rank] of PEER p's region;
+//   2. every block, lane p: poll flag[p] of its OWN region (acquire, system scope) until it holds this step's number -- peer p
+//      has published; bounded (~1 s): a peer that never arrives raises bit 4 of the error word and the block leaves without
+//      touching the weights;
+//   3. sum the world's buckets in RANK order (every rank forms the same sum, bit for bit) and apply
+//      theta <- theta - lr * (sum + L2 term) with the shadow refresh of k_update.
+// Reuse of a parity buffer is safe without a second signal: a rank rewrites bucket[n & 1] in step n + 2, after its step n + 1
+// launch saw every peer's flag n + 1, which a peer raises only after its own step-n launch (the reader of bucket[n & 1]) ended.
+// Flags only grow (64-bit step numbers): nothing is ever reset.
+// ------------------------------------------------------------------------------------------
+struct P2PArgs {
+    float* peer[8]; int world, rank; unsigned long long step; size_t bucket_off, flag_off; int* err;
+};
+
+template <typename T>
+static __global__ __launch_bounds__(256) void k_p2p_update(const P2PArgs pa, float* __restrict__ master, const float lr, const float lambda1,
+                                                    const int reg_all, const int K1p, const int H1p, const int H2p, T* __restrict__ w1,
+                                                    T* __restrict__ w1t, T* __restrict__ w2, T* __restrict__ w2t, float* __restrict__ bb0,
+                                                    const size_t nw, const size_t nbag)
+{
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_bad = 0;
+    if (blockIdx.x == 0 && tid < pa.world) {
+        unsigned long long* f = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(pa.peer[tid]) + pa.flag_off) + (size_t)pa.rank * 8;
+        __hip_atomic_store(f, pa.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (tid < pa.world) {
+        const unsigned long long* f = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(pa.peer[pa.rank]) + pa.flag_off) + (size_t)tid * 8;
+        int tries = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pa.step) {
+            if (++tries > (1 << 21)) { s_bad = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) atomicOr(pa.err, 16); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                      // system scope: the peers' buckets, not a cached older step
+    const size_t i = (size_t)blockIdx.x * 256 + tid;
+    if (i >= nw + nbag) return;
+    float g = 0.f;
+    for (int r = 0; r < pa.world; ++r) g += __builtin_nontemporal_load(pa.peer[r] + pa.bucket_off + i);
+    if (i >= nw) { bb0[i - nw] -= lr * g; return; }                    // bag bias (python/SNN_RBM.py:289)
+    const size_t n1 = (size_t)K1p * H1p, n2 = (size_t)H1p * H2p;
+    float w = master[i];
+    if (reg_all || i >= n1 + n2) g += 2.0f * lambda1 * w;
+    w -= lr * g; master[i] = w;
+    if (i < n1) {
+        const int r = (int)(i / H1p), c = (int)(i % H1p);
+        w1t[ft_off<T>(c, r, K1p)] = (T)w; w1[ft_off<T>(r, c, H1p)] = (T)w;
+    } else if (i < n1 + n2) {
+        const size_t j = i - n1;
+        const int r = (int)(j / H2p), c = (int)(j % H2p);
+        w2t[ft_off<T>(c, r, H1p)] = (T)w; w2[ft_off<T>(r, c, H2p)] = (T)w;
+    }
+}
+
 }  // namespace fnn

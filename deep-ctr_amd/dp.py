@@ -35,10 +35,15 @@ class DataParallelFNN(object):
     """Wraps an engine exposing step_begin / step_end / stream (FNNEngine on a GPU).  `group` is a
     torch.distributed process group (None = default)."""
 
-    def __init__(self, engine, group=None, sparse='local', native=None):
+    def __init__(self, engine, group=None, sparse='local', native=None, payload=None, collective='rccl'):
+        """payload: 'slabs' | 'bucket' | None (= $FNN_DP_PAYLOAD, else slabs) -- what the dense collective of the native step
+        carries; collective: 'rccl' (the library's RCCL call, or torch.distributed callbacks under another backend) or 'p2p'
+        (one-shot all-reduce over peer pointers inside the update launch; the ranks' exchange regions are opened through
+        hipIpc handles passed around with all_gather_object)."""
         import torch.distributed as dist
-        assert sparse in ('local', 'exchange')
+        assert sparse in ('local', 'exchange') and payload in (None, 'slabs', 'bucket') and collective in ('rccl', 'p2p')
         self.sparse = sparse
+        self.payload, self.want_collective = payload, collective
         self.engine = engine
         self.dist = dist
         self.group = group
@@ -72,6 +77,16 @@ class DataParallelFNN(object):
                         recv.view(self.world, -1)[i].copy_(p)
             eng.dp_init_custom(self.rank, self.world, allreduce, allgather, self.sparse)
             self.collective = 'torch.distributed/%s (library callbacks)' % dist.get_backend(self.group)
+        if self.payload is not None:
+            eng.dp_set_payload(self.payload)
+        if self.want_collective == 'p2p':
+            mine = eng.dp_p2p_export()
+            handles = [None] * self.world
+            dist.all_gather_object(handles, mine, group=self.group)
+            eng.dp_p2p_attach(handles)
+            dist.barrier(group=self.group)                     # every rank has opened every region before the first step
+            self.collective = 'p2p (peer pointers inside the update launch; region: %s)' % eng.dp_config()['region']
+        self.config = eng.dp_config()
 
     def shard(self, ids, y):
         lo, hi = shard_bounds(len(y), self.world, self.rank)

@@ -325,6 +325,33 @@ class FNNEngine(object):
         self._ck(self.lib.fnn_dp_shutdown(self.h))
         self.dp_world = 1
 
+    def dp_set_payload(self, payload):
+        """'slabs' (2 MB between launch 2 and 3, three launches) or 'bucket' (0.5 MB after launch 3, a fourth launch updates)."""
+        self._ck(self.lib.fnn_dp_set_payload(self.h, {'slabs': _capi.FNN_DP_PAYLOAD_SLABS, 'bucket': _capi.FNN_DP_PAYLOAD_BUCKET}[payload]))
+
+    def dp_p2p_export(self, same_process=False):
+        """This rank's 64-byte handle of its exchange region (fnn_dp_p2p_export); hand all ranks' handles to dp_p2p_attach."""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.fnn_dp_p2p_export(self.h, buf, 1 if same_process else 0))
+        return buf.raw
+
+    def dp_p2p_attach(self, handles, same_process=False):
+        """handles: the `world` 64-byte handles in rank order; afterwards the dense collective is the one-shot peer-pointer
+        all-reduce inside the update launch (FNN_DP_COLLECTIVE_P2P)."""
+        blob = b''.join(handles)
+        assert len(blob) == 64 * self.dp_world
+        self._ck(self.lib.fnn_dp_p2p_attach(self.h, C.c_char_p(blob), 1 if same_process else 0))
+        self._ck(self.lib.fnn_dp_set_collective(self.h, _capi.FNN_DP_COLLECTIVE_P2P))
+
+    def dp_set_collective(self, name):
+        self._ck(self.lib.fnn_dp_set_collective(self.h, _capi.FNN_DP_COLLECTIVE_P2P if name == 'p2p' else _capi.FNN_DP_COLLECTIVE_CALLBACK))
+
+    def dp_config(self):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(self.lib.fnn_dp_get_config(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {'payload': ('slabs', 'bucket')[a.value], 'collective': ('callback', 'p2p')[b.value],
+                'region': ('none', 'uncached', 'fine-grained', 'plain')[c.value]}
+
     def step_scatter(self):
         """Enqueue the sparse-row half of a begun step (overlaps an async all-reduce of the bucket)."""
         self._ck(self.lib.fnn_step_scatter(self.h))

@@ -189,6 +189,40 @@ int fnn_dp_init_custom(fnn_handle* h, int rank, int world, fnn_allreduce_fn allr
 /* Back to single-process steps (destroys the communicator).  fnn_destroy does this too. */
 int fnn_dp_shutdown(fnn_handle* h);
 
+/* What the dense collective of the native step carries, and who performs it.  Both are properties of the HANDLE, set the same
+ * way on every rank: the count and kind of the step's collectives never depend on a rank's own shard (a shard that takes the
+ * layer-by-layer kernels -- shadowed features, more than 4096 examples -- issues the same collective as its peers).
+ *   FNN_DP_PAYLOAD_SLABS    the split-K slabs of the weight gradients, reduced in place between launch 2 and launch 3
+ *                           (4 x 131,072 floats at the reference shape: 2 MB; three launches + the collective)
+ *   FNN_DP_PAYLOAD_BUCKET   launch 3 first sums this rank's slabs into the flat bucket (w1 | w2 | w3 | bag bias, padded:
+ *                           123,008 floats = 0.5 MB at the reference shape), the collective reduces the bucket, a fourth
+ *                           launch applies the update (a quarter of the bytes, one more launch)
+ * Default: $FNN_DP_PAYLOAD ("slabs" / "bucket") read at fnn_dp_init*, else slabs.  Call between steps. */
+#define FNN_DP_PAYLOAD_SLABS   0
+#define FNN_DP_PAYLOAD_BUCKET  1
+int fnn_dp_set_payload(fnn_handle* h, int payload);
+/*   FNN_DP_COLLECTIVE_CALLBACK  RCCL (fnn_dp_init) or the caller's all-reduce (fnn_dp_init_custom)
+ *   FNN_DP_COLLECTIVE_P2P       one-shot all-reduce over peer pointers INSIDE the update launch: every rank publishes its
+ *                               bucket in an exchange region the peers have mapped (hipIpc*), raises a flag in every peer's
+ *                               region, waits for the peers' flags and sums all buckets in rank order (so every rank forms the
+ *                               same sum, bit for bit).  No library collective on the dense path; the payload is the bucket.
+ *                               xGMI is point to point: each of the 7 reads of a rank's 0.5 MB uses its own link.
+ * Set-up, after fnn_dp_init / fnn_dp_init_custom (which fixes rank and world, and still serves the all-gathers of
+ * FNN_DP_SPARSE_EXCHANGE): every rank calls fnn_dp_p2p_export, the 64-byte handles are exchanged through any side channel,
+ * every rank calls fnn_dp_p2p_attach with all `world` handles in rank order (its own included), then
+ * fnn_dp_set_collective(h, FNN_DP_COLLECTIVE_P2P).  same_process != 0: the ranks are handles of ONE process (tests): a
+ * "handle" then holds the region's device pointer in its first 8 bytes and nothing is opened.
+ * A peer that does not arrive within ~1 s makes the step fail (fnn_sync / the next host read returns FNN_ERR_HIP) instead
+ * of hanging; the dense tensors of that step are left untouched. */
+#define FNN_DP_COLLECTIVE_CALLBACK 0
+#define FNN_DP_COLLECTIVE_P2P      1
+int fnn_dp_p2p_export(fnn_handle* h, void* handle64_out, int same_process);
+int fnn_dp_p2p_attach(fnn_handle* h, const void* handles, int same_process);
+int fnn_dp_set_collective(fnn_handle* h, int collective);
+/* What is in force: payload, collective, and the kind of memory the exchange region lives in (0 none, 1 uncached,
+ * 2 fine-grained, 3 plain hipMalloc). */
+int fnn_dp_get_config(fnn_handle* h, int* payload, int* collective, int* region_kind);
+
 /* Portable form, for a caller that issues the collective itself between two calls: _begin runs everything except the
  * dense SGD and leaves the dense gradients (sum over this rank's examples) in one flat f32
  * bucket; the caller all-reduces the bucket on fnn_stream(); _end applies

@@ -118,13 +118,27 @@ def test_rccl_world_one_is_the_single_gpu_step(built):
     plain.close(); dp.close()
 
 
-def _run_local(rows, fo, p, ids, y, r1, r2, kw, G, steps, cut, prefetch):
-    """`steps` native LOCAL-mode steps on two virtual ranks; returns per-rank (dense, table) and the per-step losses."""
+def _p2p_same_process(ranks):
+    """The exchange regions of engines living in this process: plain pointers instead of hipIpc handles."""
+    handles = [e.dp_p2p_export(same_process=True) for e in ranks]
+    for e in ranks:
+        e.dp_p2p_attach(handles, same_process=True)
+
+
+def _run_local(rows, fo, p, ids, y, r1, r2, kw, G, steps, cut, prefetch, payload=None, p2p=False, shadow=None):
+    """`steps` native LOCAL-mode steps on two virtual ranks; returns per-rank (dense, table) and the per-step losses.
+    payload: None (the default, slabs) / 'slabs' / 'bucket'; p2p: the dense collective is the peer-pointer all-reduce inside
+    the update launch (no callback runs); shadow: per rank, the (t, field, row) list of step 0 or None."""
     import torch
     ranks = [make_engine(rows, fo, p, **kw) for _ in range(2)]
     vr = VirtualRanks(2)
     for r, e in enumerate(ranks):
         e.dp_init_custom(r, 2, vr.allreduce_for(r), vr.allgather_for(r), sparse='local')
+        if payload is not None:
+            e.dp_set_payload(payload)
+    if p2p:
+        _p2p_same_process(ranks)
+        assert ranks[0].dp_config() == {'payload': 'bucket', 'collective': 'p2p', 'region': ranks[0].dp_config()['region']}
     dev_ids = [[torch.as_tensor(np.ascontiguousarray(ids[s * G:(s + 1) * G][c])).cuda() for s in range(steps)] for c in cut]
     losses = [[], []]
 
@@ -134,11 +148,13 @@ def _run_local(rows, fo, p, ids, y, r1, r2, kw, G, steps, cut, prefetch):
                 sl = slice(s * G, (s + 1) * G)
                 if prefetch and s + 1 < steps:
                     ranks[r].prefetch_ids(dev_ids[r][s + 1])
+                if shadow is not None and s == 0 and shadow[r] is not None:
+                    ranks[r].set_shadowed(shadow[r])
                 out = ranks[r].train_step(dev_ids[r][s], y[sl][cut[r]], r1, r2, b_size=G)
                 losses[r].append(out['loss'])
         return go
     vr.run([rank_fn(0), rank_fn(1)])
-    assert vr.calls['allreduce'] == steps and vr.calls['allgather'] == 0
+    assert vr.calls['allreduce'] == (0 if p2p else steps) and vr.calls['allgather'] == 0
     state = [(e.get_dense(), e.get_table()) for e in ranks]
     for e in ranks:
         e.close()
@@ -321,3 +337,125 @@ def test_scatter_global_at_eight_times_4096(built):
     untouched = np.setdiff1d(np.arange(rows.shape[0]), np.unique(ids[ids >= 0]))
     assert np.array_equal(got[untouched], rows[untouched].astype(np.float32))
     eng.close()
+
+
+# ----------------------------------------------------------------- round 3: what the collective carries, and who performs it
+def test_world_one_bucket_payload_and_p2p_are_the_single_gpu_step(built):
+    """World size 1, where every collective is the identity: the bucket payload (launch 3 without its update, RCCL all-reduce
+    of the 0.5 MB bucket, k_update) and the p2p collective (k_p2p_update summing the one region) leave, after three steps, the
+    bitwise state of a plain engine -- the same sums in the same order, the same update arithmetic."""
+    rows, fo, ids, y, p, r1, r2 = make_problem(3 * 700, seed=52, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.02, lamfm=0.1)
+    plain, bk, pp = (make_engine(rows, fo, p, **kw) for _ in range(3))
+    bk.dp_init(0, 1, FNNEngine.dp_unique_id())
+    bk.dp_set_payload('bucket')
+    pp.dp_init(0, 1, FNNEngine.dp_unique_id())
+    _p2p_same_process([pp])
+    assert bk.dp_config()['payload'] == 'bucket' and pp.dp_config()['collective'] == 'p2p'
+    for e in (bk, pp):
+        e.prof_enable(True)
+    for s in range(3):
+        sl = slice(s * 700, (s + 1) * 700)
+        a = plain.train_step(ids[sl], y[sl], r1, r2)
+        for e in (bk, pp):
+            assert e.train_step(ids[sl], y[sl], r1, r2, b_size=700)['loss'] == a['loss']
+    assert bk.prof_get('allreduce')[1] == 3 and pp.prof_get('allreduce')[1] == 0 and pp.prof_get('p2p_update')[1] == 3
+    da = plain.get_dense()
+    for e in (bk, pp):
+        db = e.get_dense()
+        for k in da:
+            assert np.array_equal(da[k], db[k]), k
+        assert np.array_equal(plain.get_table(), e.get_table())
+    for e in (plain, bk, pp):
+        e.close()
+
+
+def test_two_virtual_ranks_payload_and_collective_variants(built):
+    """Two virtual ranks, three LOCAL steps, in the three forms the step can take: slabs through the callback, bucket through the
+    callback, bucket through peer pointers.  Every form tracks ONE engine stepping the global batch (first step: the replicas'
+    tables still agree); inside a form both ranks hold bit-identical dense tensors (every rank forms the same sum); the two
+    bucket forms are bit-identical to EACH OTHER (the callback double and the kernel both add the ranks' buckets in rank order)."""
+    G, steps = 1000, 3
+    rows, fo, ids, y, p, r1, r2 = make_problem(steps * G, seed=65, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.05, lamfm=0.1)
+    full = make_engine(rows, fo, p, **kw)
+    ref_loss = full.train_step(ids[:G], y[:G], r1, r2)['loss']
+    ref_dense = full.get_dense()
+    full.close()
+    cut = [slice(0, 512), slice(512, G)]
+    first = {}
+    for name, kws in (('slabs', dict(payload='slabs')), ('bucket', dict(payload='bucket')), ('p2p', dict(p2p=True))):
+        st1, l1 = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False, **kws)
+        assert abs(l1[0][0] + l1[1][0] - ref_loss) <= 2e-5 * abs(ref_loss), name
+        for dense, _ in st1:
+            _dense_close(dense, ref_dense, p)
+        first[name] = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, steps, cut, True, **kws)
+        (d0, _), (d1, _) = first[name][0]
+        for k in d0:
+            assert np.array_equal(d0[k], d1[k]), (name, k)
+    (sa, la), (sb, lb) = first['bucket'], first['p2p']
+    assert la == lb
+    for (da, ta), (db, tb) in zip(sa, sb):
+        assert np.array_equal(ta, tb)
+        for k in da:
+            assert np.array_equal(da[k], db[k]), k
+
+
+@pytest.mark.parametrize("form", ['slabs', 'bucket', 'p2p'])
+@pytest.mark.parametrize("why", ['shadowed', 'ragged'])
+def test_a_rank_on_the_layer_by_layer_path_pairs_with_fast_peers(built, form, why):
+    """Round-2 advisor: the collective must not depend on a rank's own shard.  Rank 0 is pushed to the layer-by-layer kernels
+    -- by shadowed features in ITS shard only, or by a shard above 4096 examples beside one below -- while rank 1 takes the
+    three-launch path.  Both issue the same collective (no hang, no mismatched count) and both end with the dense tensors of
+    one engine stepping the global batch."""
+    import torch
+    if why == 'shadowed':
+        G, cut, mb = 1000, [slice(0, 512), slice(512, 1000)], 4096
+    else:
+        G, cut, mb = 7500, [slice(0, 4500), slice(4500, 7500)], 16384
+    rows, fo, ids, y, p, r1, r2 = make_problem(G, seed=91, dup_col=6)
+    kw = dict(lr=0.01, lam1=0.05, lamfm=0.1, max_batch=mb)
+    shadow = None
+    if why == 'shadowed':
+        # rank 0's examples 3, 4 and 9 carry a second feature of field 2 (another row of that field), shadowed in the gather
+        rows_f2 = np.nonzero(fo == 2)[0]
+        shadow = [np.array([(t, 2, int(rows_f2[(t + 1) % len(rows_f2)])) for t in (3, 4, 9)], np.int32), None]
+    full = make_engine(rows, fo, p, **kw)
+    if shadow is not None:
+        full.set_shadowed(shadow[0])
+    ref_loss = full.train_step(ids, y, r1, r2)['loss']
+    ref_dense, ref_rows = full.get_dense(), full.get_table()
+    full.close()
+    kws = dict(p2p=True) if form == 'p2p' else dict(payload=form)
+    state, losses = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False, shadow=shadow, **kws)
+    assert abs(losses[0][0] + losses[1][0] - ref_loss) <= 3e-5 * abs(ref_loss)
+    for dense, _ in state:
+        _dense_close(dense, ref_dense, p, tol=5e-4)
+    for k in state[0][0]:
+        assert np.array_equal(state[0][0][k], state[1][0][k]), k
+    if shadow is not None:                                   # the shadowed rows moved on rank 0 (and only there)
+        sh_rows = shadow[0][:, 2]
+        assert np.all(np.abs(state[0][1][sh_rows] - rows[sh_rows]).max(axis=1) > 0)
+        change = np.abs(ref_rows - rows.astype(np.float32)).max()
+        only0 = np.array(sorted(set(sh_rows) - set(np.unique(ids[cut[1]]))))
+        assert np.abs(state[0][1][only0] - ref_rows[only0]).max() <= 3e-4 * change + 1e-7
+
+
+def test_p2p_missing_peer_fails_loudly_and_leaves_the_weights(built):
+    """A peer that never reaches the step: the update launch gives up after ~2^21 polls, raises the error word, and the dense
+    tensors keep their values; the next host read reports FNN_ERR_HIP instead of hanging."""
+    from deep_ctr_amd.engine import FNNError
+    rows, fo, ids, y, p, r1, r2 = make_problem(300, seed=93)
+    ranks = [make_engine(rows, fo, p) for _ in range(2)]
+    for r, e in enumerate(ranks):
+        e.dp_init_custom(r, 2, lambda v: None, None, sparse='local')
+    _p2p_same_process(ranks)
+    before = ranks[0].get_dense()
+    with pytest.raises(FNNError) as e:
+        ranks[0].train_step(ids, y, r1, r2, b_size=600)      # rank 1 never steps
+    assert 'peer' in str(e.value)
+    after = ranks[0].get_dense()
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    for e in ranks:
+        e.close()
