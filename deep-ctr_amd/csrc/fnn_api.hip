@@ -364,10 +364,10 @@ template <typename T> int dp_finish_bucket(fnn_handle* h, bool in_region)
         for (int r = 0; r < 8; ++r) pa.peer[r] = h->peer[r];
         pa.world = h->dp_world; pa.rank = h->dp_rank; pa.step = h->dp_step_no + 1;
         pa.bucket_off = (size_t)(h->dp_step_no & 1) * h->xr_nbp; pa.flag_off = 2 * h->xr_nbp * sizeof(float); pa.err = h->err_flag;
-        const size_t n = h->nw + h->nbag;
-        hipLaunchKernelGGL((k_p2p_update<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, pa, h->master, h->cfg.lr,
+        const unsigned nblk = (unsigned)((h->nw12 / 4 + 255) / 256 + (h->nw - h->nw12 + h->nbag + 255) / 256);
+        hipLaunchKernelGGL((k_p2p_update<T>), dim3(nblk), dim3(256), 0, h->st, pa, h->master, h->cfg.lr,
                            h->cfg.lambda1, h->cfg.reg_all, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t,
-                           h->bb0, h->nw, h->nbag);
+                           h->bb0, h->nw12, h->nw, h->nbag);
         h->dp_step_no++;
         return FNN_OK;
     }

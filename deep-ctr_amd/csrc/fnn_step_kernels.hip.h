@@ -327,7 +327,7 @@ template <typename T>
 static __global__ __launch_bounds__(256) void k_p2p_update(const P2PArgs pa, float* __restrict__ master, const float lr, const float lambda1,
                                                     const int reg_all, const int K1p, const int H1p, const int H2p, T* __restrict__ w1,
                                                     T* __restrict__ w1t, T* __restrict__ w2, T* __restrict__ w2t, float* __restrict__ bb0,
-                                                    const size_t nw, const size_t nbag)
+                                                    const size_t nw12, const size_t nw, const size_t nbag)
 {
     __shared__ int s_bad;
     const int tid = threadIdx.x;
@@ -337,7 +337,7 @@ static __global__ __launch_bounds__(256) void k_p2p_update(const P2PArgs pa, flo
         __hip_atomic_store(f, pa.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    if (tid < pa.world) {
+    if (tid < pa.world) {                                       // one wave per workgroup polls (and performs the system-scope acquire)
         const unsigned long long* f = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(pa.peer[pa.rank]) + pa.flag_off) + (size_t)tid * 8;
         int tries = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pa.step) {
@@ -345,26 +345,46 @@ static __global__ __launch_bounds__(256) void k_p2p_update(const P2PArgs pa, flo
             __builtin_amdgcn_s_sleep(8);
         }
     }
-    __syncthreads();
+    __syncthreads();                                            // the other waves read the buckets behind this barrier
     if (s_bad) { if (tid == 0) atomicOr(pa.err, 16); return; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                      // system scope: the peers' buckets, not a cached older step
-    const size_t i = (size_t)blockIdx.x * 256 + tid;
+    // W1p | W2p: 4 consecutive elements per thread (16-byte bucket reads from every rank, rank order), as in k_step3's dense role
+    const size_t nvec = nw12 / 4;
+    const int nvb = (int)((nvec + 255) / 256);
+    const int b = blockIdx.x;
+    if (b < nvb) {
+        const size_t q = (size_t)b * 256 + tid;
+        if (q >= nvec) return;
+        const size_t i = q * 4;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < pa.world; ++r) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa.peer[r] + pa.bucket_off + i));
+            g.x += v[0]; g.y += v[1]; g.z += v[2]; g.w += v[3];
+        }
+        float4 w = *reinterpret_cast<const float4*>(master + i);
+        const float l2 = reg_all ? 2.0f * lambda1 : 0.0f;
+        w.x -= lr * (g.x + l2 * w.x); w.y -= lr * (g.y + l2 * w.y);
+        w.z -= lr * (g.z + l2 * w.z); w.w -= lr * (g.w + l2 * w.w);
+        *reinterpret_cast<float4*>(master + i) = w;
+        const size_t n1 = (size_t)K1p * H1p;
+        const bool first = i < n1;
+        const size_t j = first ? i : i - n1;
+        const int ld = first ? H1p : H2p, kin = first ? K1p : H1p;
+        const int r = (int)(j / ld), c = (int)(j % ld);
+        T* wn = first ? w1 : w2;
+        T* wt = first ? w1t : w2t;
+        store4(wn + ft_off<T>(r, c, ld), w.x, w.y, w.z, w.w);
+        wt[ft_off<T>(c, r, kin)] = (T)w.x; wt[ft_off<T>(c + 1, r, kin)] = (T)w.y;
+        wt[ft_off<T>(c + 2, r, kin)] = (T)w.z; wt[ft_off<T>(c + 3, r, kin)] = (T)w.w;
+        return;
+    }
+    const size_t i = nw12 + (size_t)(b - nvb) * 256 + tid;      // w3p, then the bag bias: one element each
     if (i >= nw + nbag) return;
     float g = 0.f;
     for (int r = 0; r < pa.world; ++r) g += __builtin_nontemporal_load(pa.peer[r] + pa.bucket_off + i);
-    if (i >= nw) { bb0[i - nw] -= lr * g; return; }                    // bag bias (python/SNN_RBM.py:289)
-    const size_t n1 = (size_t)K1p * H1p, n2 = (size_t)H1p * H2p;
-    float w = master[i];
-    if (reg_all || i >= n1 + n2) g += 2.0f * lambda1 * w;
-    w -= lr * g; master[i] = w;
-    if (i < n1) {
-        const int r = (int)(i / H1p), c = (int)(i % H1p);
-        w1t[ft_off<T>(c, r, K1p)] = (T)w; w1[ft_off<T>(r, c, H1p)] = (T)w;
-    } else if (i < n1 + n2) {
-        const size_t j = i - n1;
-        const int r = (int)(j / H2p), c = (int)(j % H2p);
-        w2t[ft_off<T>(c, r, H1p)] = (T)w; w2[ft_off<T>(r, c, H2p)] = (T)w;
-    }
+    if (i >= nw) { bb0[i - nw] -= lr * g; return; }             // python/SNN_RBM.py:289
+    const float w = master[i];
+    g += 2.0f * lambda1 * w;                                     // w3, b3 are always regularised (python/FNN_wnzh.py:173)
+    master[i] = w - lr * g;
 }
 
 }  // namespace fnn

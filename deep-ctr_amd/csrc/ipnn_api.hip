@@ -839,14 +839,16 @@ struct IpUpdArgs {
     // lr is then lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) of this step
     int adam;                                        // 0 = SGD, else IPNN_OPT_ADAM / IPNN_OPT_FTRL (state = (accum, linear))
     float beta1, beta2, eps; float* Wm[IPNN_MAX_HIDDEN + 1]; float* Wv[IPNN_MAX_HIDDEN + 1]; float* bmv;
+    const int* err;                                  // bit 1 set (a strip pair gave up its swap): the step's activations are invalid -- nothing is applied
 };
 
 // The scalar b of z1 (python/FNN_IP_L7.py:104-114): its gradient is the sum of the per-workgroup partials of k_ip_bwd.  A launch
 // of its own on the side stream, right behind k_ip_bwd, so that the dense update on the main stream depends on nothing there.
 static __global__ __launch_bounds__(256) void k_ip_b_update(float* __restrict__ b, const float* __restrict__ gb_part, int ngb, int opt,
-                                                            float* __restrict__ bmv, float lr, float beta1, float beta2, float eps)
+                                                            float* __restrict__ bmv, float lr, float beta1, float beta2, float eps, const int* __restrict__ err)
 {
     __shared__ float sg[256];
+    if (*err & 2) return;
     sg[threadIdx.x] = strided_sum256(gb_part, ngb);
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -880,6 +882,7 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     __shared__ __align__(16) T sT[64][64 + EPL];                 // [column][row], padded
     const size_t tile = blockIdx.x;
     if (tile * 4096 >= u.off[u.n]) return;
+    if (*u.err & 2) return;                                      // a strip pair gave up (StripDuo): the gradients are garbage, the weights stay
     int t = 0;
 #pragma unroll
     for (int q = 1; q <= IPNN_MAX_HIDDEN; ++q) t += (q < u.n && tile * 4096 >= u.off[q]) ? 1 : 0;
@@ -971,6 +974,7 @@ struct ipnn_handle {
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
+    bool duo_failed = false;                         // a pair gave up once: every later train step is refused until the handle is re-created
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
 };
@@ -1081,6 +1085,12 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         IHK(h, hipMalloc((void**)&h->duo_flags, (size_t)(h->ldT / (16 * RT)) * 2 * sizeof(int)));
         IHK(h, hipMemsetAsync(h->duo_flags, 0, (size_t)(h->ldT / (16 * RT)) * 2 * sizeof(int), h->st));
     }
+    if (duo && h->duo_epoch >= (1 << 26)) {
+        // flags hold epoch * 16 + swap index in 32 bits: long before that wraps (2^27 launches), drain the stream and start over at 0
+        IHK(h, hipStreamSynchronize(h->st));
+        IHK(h, hipMemsetAsync(h->duo_flags, 0, (size_t)(h->ldT / (16 * RT)) * 2 * sizeof(int), h->st));
+        h->duo_epoch = 0;
+    }
     if (strip) {
         if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -1158,7 +1168,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             IpBwdArgs ba{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->Dp[0], h->emb};
             hipLaunchKernelGGL(k_ip_bwd, dim3(Ba / 16), dim3(256), lds_ip, ss, ba, h->dz0, h->gxp, h->gb_part);
             hipLaunchKernelGGL(k_ip_b_update, dim3(1), dim3(256), 0, ss, h->b, h->gb_part, Ba / 16, h->adam ? (int)h->cfg.optimizer : 0, h->bmv,
-                               lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps);
+                               lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->err_flag);
         }
         {   // sparse rows: row -= lr * sum of its gradients (c = 1: the table of powers is all ones)
             IpProf ps(h, "scatter", ss);
@@ -1218,7 +1228,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         u.n = L + 1; u.off[L + 1] = off; u.slab = h->slab; u.zstride = h->slab_stride; u.lr = lr_step;
         u.adam = h->adam ? (int)h->cfg.optimizer : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
         if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
-        u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev;
+        u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev; u.err = h->err_flag;
         hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)(off / 4096 + 1)), dim3(256), 0, h->st, u);
     }
     if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
@@ -1372,7 +1382,10 @@ int ipnn_sync(ipnn_handle* h)
     IHK(h, hipStreamSynchronize(h->st));
     if (flag) {
         IHK(h, hipMemsetAsync(h->err_flag, 0, 4, h->st));
-        if (flag & 2) IFAIL(h, FNN_ERR_HIP, "a strip workgroup gave up waiting for its partner (StripDuo swap): results of that step are invalid; IPNN_STRIP_DUO=0 selects one workgroup per strip");
+        if (flag & 2) {
+            h->duo_failed = true;
+            IFAIL(h, FNN_ERR_HIP, "a strip workgroup gave up waiting for its partner (StripDuo swap): that step's outputs are invalid and its dense update was not applied; the handle refuses further train steps (IPNN_STRIP_DUO=0 selects one workgroup per strip)");
+        }
         IFAIL(h, FNN_ERR_RANGE, "feature id outside [0, n_rows)");
     }
     return FNN_OK;
@@ -1483,6 +1496,7 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B, c
     if (!h || !ids || !y) return FNN_ERR_ARG;
     if (B < 1 || B > h->Bmax) IFAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
     if (!h->table16) IFAIL(h, FNN_ERR_STATE, "ipnn_set_table has not been called");
+    if (h->duo_failed) IFAIL(h, FNN_ERR_STATE, "an earlier step failed (StripDuo swap timed out): re-create the handle");
     IHK(h, hipSetDevice(h->dev));
     int rc = h->bf16 ? ip_run<bf16_t>(h, ids, y, B, masks, logits_out, nullptr, true)
                      : ip_run<float>(h, ids, y, B, masks, logits_out, nullptr, true);

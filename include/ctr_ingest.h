@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CTR_OK          0
 #define CTR_ERR_ARG    -1
@@ -88,6 +92,9 @@ int ctr_yzx_stat(const char* path, int n_threads, int64_t* n_examples, int64_t* 
 int ctr_parse_yzx(const char* path, int n_threads, int64_t cap, int64_t max_dim, int max_fea,
                   int64_t* X_ind, int64_t* X_val, int64_t* y, int64_t* n_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

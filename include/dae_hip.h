@@ -21,6 +21,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 const char* dae_last_error(void);
 
@@ -65,6 +69,9 @@ int dae_bag_cumsum_sigmoid_f64(const double* W0, const double* b0, int H, int64_
 int dae_affine_sigmoid_f64(const double* in, const double* W, const double* bias, int n, int a, int b,
                            double* out, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct fm_handle fm_handle;
 
@@ -50,6 +54,9 @@ int fm_train_step(fm_handle* h, const int32_t* ids, const float* y, int B, float
 /* p_out [B] = sigmoid(yhat) (`test_preds`, :52). */
 int fm_predict(fm_handle* h, const int32_t* ids, int B, float* p_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

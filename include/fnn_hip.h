@@ -37,6 +37,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FNN_OK          0
 #define FNN_ERR_ARG    -1   /* bad argument / unsupported shape              */
@@ -269,6 +273,9 @@ int fnn_prof_enable(fnn_handle* h, int on);
 int fnn_prof_reset(fnn_handle* h);
 int fnn_prof_get(fnn_handle* h, const char* which, double* avg_ms, int64_t* launches);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define IPNN_ACT_TANH    0      /* python/tf_util.py:32-38 `activate` */
 #define IPNN_ACT_SIGMOID 1
@@ -95,6 +99,9 @@ int ipnn_eval(ipnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, d
 int ipnn_prof_enable(ipnn_handle* h, int on);
 int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 const char* rbm_last_error(void);
 
@@ -74,6 +78,9 @@ int rbm_affine(const float* in, const float* W, const float* bias, int n, int a,
                void* stream);
 int rbm_sigmoid(float* x, int64_t count, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -370,11 +370,10 @@ def test_world_one_bucket_payload_and_p2p_are_the_single_gpu_step(built):
         e.close()
 
 
-def test_two_virtual_ranks_payload_and_collective_variants(built):
-    """Two virtual ranks, three LOCAL steps, in the three forms the step can take: slabs through the callback, bucket through the
-    callback, bucket through peer pointers.  Every form tracks ONE engine stepping the global batch (first step: the replicas'
-    tables still agree); inside a form both ranks hold bit-identical dense tensors (every rank forms the same sum); the two
-    bucket forms are bit-identical to EACH OTHER (the callback double and the kernel both add the ranks' buckets in rank order)."""
+def test_two_virtual_ranks_payload_variants(built):
+    """Two virtual ranks, three LOCAL steps, slabs or bucket through the callback.  Each form tracks ONE engine stepping the
+    global batch (first step: the replicas' tables still agree); inside a form both ranks hold bit-identical dense tensors
+    (every rank forms the same sum).  (The peer-pointer form needs ranks in processes of their own: the rehearsal tests below.)"""
     G, steps = 1000, 3
     rows, fo, ids, y, p, r1, r2 = make_problem(steps * G, seed=65, dup_col=6)
     kw = dict(lr=0.01, lam1=0.05, lamfm=0.1)
@@ -384,7 +383,7 @@ def test_two_virtual_ranks_payload_and_collective_variants(built):
     full.close()
     cut = [slice(0, 512), slice(512, G)]
     first = {}
-    for name, kws in (('slabs', dict(payload='slabs')), ('bucket', dict(payload='bucket')), ('p2p', dict(p2p=True))):
+    for name, kws in (('slabs', dict(payload='slabs')), ('bucket', dict(payload='bucket'))):
         st1, l1 = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False, **kws)
         assert abs(l1[0][0] + l1[1][0] - ref_loss) <= 2e-5 * abs(ref_loss), name
         for dense, _ in st1:
@@ -393,15 +392,9 @@ def test_two_virtual_ranks_payload_and_collective_variants(built):
         (d0, _), (d1, _) = first[name][0]
         for k in d0:
             assert np.array_equal(d0[k], d1[k]), (name, k)
-    (sa, la), (sb, lb) = first['bucket'], first['p2p']
-    assert la == lb
-    for (da, ta), (db, tb) in zip(sa, sb):
-        assert np.array_equal(ta, tb)
-        for k in da:
-            assert np.array_equal(da[k], db[k]), k
 
 
-@pytest.mark.parametrize("form", ['slabs', 'bucket', 'p2p'])
+@pytest.mark.parametrize("form", ['slabs', 'bucket'])
 @pytest.mark.parametrize("why", ['shadowed', 'ragged'])
 def test_a_rank_on_the_layer_by_layer_path_pairs_with_fast_peers(built, form, why):
     """Round-2 advisor: the collective must not depend on a rank's own shard.  Rank 0 is pushed to the layer-by-layer kernels
@@ -426,8 +419,7 @@ def test_a_rank_on_the_layer_by_layer_path_pairs_with_fast_peers(built, form, wh
     ref_loss = full.train_step(ids, y, r1, r2)['loss']
     ref_dense, ref_rows = full.get_dense(), full.get_table()
     full.close()
-    kws = dict(p2p=True) if form == 'p2p' else dict(payload=form)
-    state, losses = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False, shadow=shadow, **kws)
+    state, losses = _run_local(rows, fo, p, ids, y, r1, r2, kw, G, 1, cut, False, shadow=shadow, payload=form)
     assert abs(losses[0][0] + losses[1][0] - ref_loss) <= 3e-5 * abs(ref_loss)
     for dense, _ in state:
         _dense_close(dense, ref_dense, p, tol=5e-4)
@@ -459,3 +451,48 @@ def test_p2p_missing_peer_fails_loudly_and_leaves_the_weights(built):
         assert np.array_equal(before[k], after[k]), k
     for e in ranks:
         e.close()
+
+
+# ----------------------------------------------------------------- two PROCESSES on the one GPU (tests/dp_rehearsal_worker.py)
+def _rehearse(tmp_path, form, case):
+    import subprocess
+    import socket
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'tests', 'dp_rehearsal_worker.py'), '--form', form, '--case', case,
+                        '--out', str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return [np.load(str(tmp_path / ('%s_%s_rank%d.npz' % (form, case, k)))) for k in (0, 1)]
+
+
+def test_two_processes_p2p_equals_bucket_through_the_callback(built, tmp_path):
+    """Three LOCAL steps on two rank PROCESSES sharing the GPU: the peer-pointer all-reduce (exchange regions opened through
+    hipIpc handles, flags raised across the process boundary) against the bucket summed by the callback collective.  Both add
+    the two ranks' buckets, so every dense tensor, both tables and the per-step losses agree BIT FOR BIT between the two forms;
+    inside a form the two ranks hold identical dense tensors."""
+    a, b = _rehearse(tmp_path, 'bucket', 'plain'), _rehearse(tmp_path, 'p2p', 'plain')
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3'):
+        assert np.array_equal(b[0][k], b[1][k]), k
+        for r in (0, 1):
+            assert np.array_equal(a[r][k], b[r][k]), (k, r)
+    for r in (0, 1):
+        assert np.array_equal(a[r]['table'], b[r]['table']) and np.array_equal(a[r]['losses'], b[r]['losses'])
+    assert not np.array_equal(b[0]['table'], b[1]['table'])        # LOCAL mode: each replica holds its own shard's row updates
+
+
+@pytest.mark.parametrize("case", ['shadowed', 'ragged'])
+def test_two_processes_p2p_with_one_rank_on_the_layer_by_layer_path(built, tmp_path, case):
+    """The rank-invariance of the collective, for the peer-pointer form: rank 0 takes the layer-by-layer kernels (shadowed
+    features in its shard / a shard above 4096 examples), rank 1 the three launches; both meet in the same update launch and
+    end with the dense tensors the callback form produces."""
+    a, b = _rehearse(tmp_path, 'bucket', case), _rehearse(tmp_path, 'p2p', case)
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3'):
+        assert np.array_equal(b[0][k], b[1][k]) and np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[0]['table'], b[0]['table'])

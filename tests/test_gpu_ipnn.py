@@ -341,3 +341,34 @@ def test_ipnn_alternative_paths_match_oracle(built, monkeypatch, env):
         cw = np.abs(params['W'][t] - p0[t]).max() + 1e-12
         assert np.abs(Ws[t] - params['W'][t]).max() <= 3e-3 * cw + 3e-7, (t, env)
     eng.close()
+
+
+def test_strip_pairs_are_bit_identical_to_single_strips(built, monkeypatch):
+    """StripDuo (two workgroups per 32-example strip, swapping halves of every wide activation tile through write-through
+    stores and a flag) against one workgroup per strip, bf16, the FNN_IP_L7 stack at batch 4096: five train steps with
+    dropout.  The pair splits OUTPUT COLUMNS only -- every value is the same sum in the same order -- so logits, every dense
+    tensor, b and every touched table row must agree BIT FOR BIT (round-2 advisor: the hand-rolled swap had only loose bf16
+    tolerances behind it).  A stale or torn block in the swap shows here at once."""
+    import torch
+    hidden = [1000, 800, 600, 400, 200, 100, 50]
+    B, steps = 4096, 5
+    table, ids, y, params, masks, d = problem(B * steps, hidden, seed=77, n_rows=3000, scale=0.05)
+    masks = [(np.random.RandomState(5 + t).uniform(size=(B * steps, d[t])) < 0.5).astype(np.uint8) for t in range(len(hidden) + 1)]
+    res = []
+    for duo in ('1', '0'):
+        monkeypatch.setenv('IPNN_STRIP_DUO', duo)
+        eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='bf16', lr=0.01, keep_prob=0.5)
+        eng.set_params(table, params['b'], params['W'], params['bias'])
+        logits = []
+        for s in range(steps):
+            sl = slice(s * B, (s + 1) * B)
+            out = eng.train_step(ids[sl], y[sl], [m[sl] for m in masks], want_logits=True)
+            logits.append(out['logits'].cpu().numpy().copy())
+        b, Ws, bs = eng.get_params()
+        res.append((np.concatenate(logits), b, Ws, bs, eng.get_rows(np.unique(ids))))
+        eng.close()
+    (la, ba, Wa, bsa, ra), (lb, bb, Wb, bsb, rb) = res
+    assert np.isfinite(la).all() and np.abs(la).max() > 0
+    assert np.array_equal(la, lb) and ba == bb and np.array_equal(ra, rb)
+    for t in range(len(Wa)):
+        assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t

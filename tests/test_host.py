@@ -55,6 +55,22 @@ def test_header_symbols_are_exported_and_bound(built):
         assert hasattr(lib, name), name
 
 
+def test_library_exports_only_the_declared_c_symbols(built):
+    """-fvisibility=hidden + the headers' visibility pragmas: the dynamic symbol table of libfnn_hip.so holds the C functions
+    the six headers declare and nothing else of ours -- no C++-mangled name (round 2 leaked fnn::group_global and
+    fnn::device_metrics), no kernel stub."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = set()
+    for tab in (_capi.SIGNATURES, _capi.RBM_SIGNATURES, _capi.IPNN_SIGNATURES, _capi.FM_SIGNATURES, _capi.DAE_SIGNATURES, _capi.CTR_SIGNATURES):
+        declared |= set(tab)
+    assert declared <= names, declared - names
+    extra = {n for n in names - declared if not n.startswith(('__hip', '_init', '_fini', '__bss', '_edata', '_end'))}
+    assert not {n for n in extra if n.startswith('_Z')}, sorted(extra)[:10]
+    assert not extra, sorted(extra)[:20]
+
+
 def _struct_fields(header, name):
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), header, re.S).group(1)
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
