@@ -1036,7 +1036,7 @@ def pmc_traffic(kernel, snn=False):
 def pmc_traffic_gather(variant):
     """HBM bytes per launch of the standalone gather kernels, per variant (ids distribution / examples per launch), from the newest
     committed counter passes (profiles/*_pmc_traffic_gather.json, written by tools/pmc_gather.sh: one variant per process, FETCH_SIZE
-    and WRITE_SIZE in separate passes; FETCH doubled as in pmc_traffic)."""
+    and WRITE_SIZE in separate passes)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_gather.json')))
     if not files:
@@ -1044,7 +1044,12 @@ def pmc_traffic_gather(variant):
     v = json.load(open(files[-1])).get(variant)
     if not v or 'FETCH_SIZE_KB_per_launch' not in v or 'WRITE_SIZE_KB_per_launch' not in v:
         return None
-    return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+    # FETCH_SIZE on gfx950 halves WIDE coalesced reads only; other widths want a calibration on a known byte count
+    # (MI355X_MICROARCH.md, HBM).  The uniform-id variants are that calibration (profiles/r03_pmc_traffic_gather.json): A3's 64-byte
+    # rows (4 lanes x 16 B) -- 262,144 random rows = 16.8 MB + 1 MB of ids expected, 16.4 MB counted: factor 1; A8's 800-byte rows
+    # (50 lanes x 16 B, 7.25 128-byte lines each) -- 243 MB expected, 120 MB counted: factor 2.
+    factor = 1.0 if variant.startswith('fm') else 2.0
+    return (factor * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
 
 
 def pmc_traffic_ipnn(seg):

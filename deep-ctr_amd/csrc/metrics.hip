@@ -8,8 +8,8 @@
 // statistic with ties counted 1/2, which is what the trapezoid rule over distinct thresholds gives.
 // The sums are 64-bit integer atomics: order-independent, bitwise reproducible.  RMSE and logloss
 // accumulate in f64 with a fixed-shape tree per block and a fixed-order sum of the block partials.
-// The key sort is rocPRIM's device radix sort (a library sort for the metric pass; no hot-path
-// kernel goes through a library).
+// The key sort of the METRIC pass is rocPRIM's device radix sort (a library sort for the metric pass; no hot-path
+// kernel goes through a library).  The groupings of the update paths use this file's own radix sort.
 #include "metrics.hip.h"
 
 #include <cstring>
@@ -82,6 +82,98 @@ __global__ __launch_bounds__(MB) void k_metric_auc(const uint32_t* __restrict__ 
     if (threadIdx.x == 0 && s_a[0]) atomicAdd(acc, s_a[0]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Stable LSD radix sort of independent SEGMENTS of 64-bit keys, 8 bits per pass (metrics.hip.h: radix_sort_segments).  The
+// groupings this library needs are "sort by row, keep the order of arrival inside a row" over 32,768 .. a few million keys:
+// the keys are generated in arrival order, so a STABLE sort on the row bits alone is the whole job (3 passes for 937,670
+// rows).  Per pass three launches over (tile, segment): digit histogram of every tile of 2,048 keys; exclusive scan of a
+// segment's [digit][tile] counts (one workgroup per segment); scatter, in which a key's place inside its tile's share of a digit
+// is its rank among the tile's keys of that digit IN TILE ORDER: a wave owns 512 consecutive keys, a wave instruction 64
+// consecutive ones, and the lanes holding the same digit find each other with eight ballots (one per digit bit) -- the lowest
+// such lane bumps the wave's counter of the digit, everyone else reads its rank off the ballot mask.  No atomics on global
+// memory, no dependence on scheduling: the result is bit-reproducible.
+// ------------------------------------------------------------------------------------------
+constexpr int RS_TILE = 2048, RS_ITEMS = 8;
+
+__global__ __launch_bounds__(256) void k_rs_hist(const unsigned long long* __restrict__ keys, int n, int shift, int nblk, unsigned* __restrict__ hist)
+{
+    __shared__ unsigned s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long* seg = keys + (size_t)blockIdx.y * n;
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(unsigned)(seg[i] >> shift) & 255u], 1u);          // LDS integer atomics: counts, order-free
+    }
+    __syncthreads();
+    hist[((size_t)blockIdx.y * 256 + threadIdx.x) * nblk + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// one workgroup per segment, thread = digit: counts [digit][tile] -> exclusive prefix in (digit, tile) order
+__global__ __launch_bounds__(256) void k_rs_scan(unsigned* __restrict__ hist, int nblk)
+{
+    __shared__ unsigned s_t[256];
+    unsigned* h = hist + ((size_t)blockIdx.x * 256 + threadIdx.x) * nblk;
+    unsigned tot = 0;
+    for (int b = 0; b < nblk; ++b) tot += h[b];
+    s_t[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                       // inclusive scan over the 256 digit totals
+        const unsigned v = (int)threadIdx.x >= o ? s_t[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s_t[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = s_t[threadIdx.x] - tot;
+    for (int b = 0; b < nblk; ++b) { const unsigned c = h[b]; h[b] = run; run += c; }
+}
+
+__global__ __launch_bounds__(256) void k_rs_scatter(const unsigned long long* __restrict__ keys_in, unsigned long long* __restrict__ keys_out,
+                                                    int n, int shift, int nblk, const unsigned* __restrict__ hist)
+{
+    __shared__ unsigned s_cnt[4][256];                         // per wave: keys of each digit seen so far (then: in all)
+    __shared__ unsigned s_base[256];                           // where this tile's keys of a digit start in the segment
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long* seg = keys_in + (size_t)blockIdx.y * n;
+    unsigned long long* out = keys_out + (size_t)blockIdx.y * n;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cnt[w][tid] = 0;
+    s_base[tid] = hist[((size_t)blockIdx.y * 256 + tid) * nblk + blockIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE + wave * (RS_TILE / 4);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long key[RS_ITEMS]; unsigned pre[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) { const int i = base + k * 64 + lane; key[k] = i < n ? seg[i] : 0ull; }
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const bool valid = base + k * 64 + lane < n;
+        const unsigned d = (unsigned)(key[k] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const unsigned long long bb = __ballot((d >> b) & 1u); m &= ((d >> b) & 1u) ? bb : ~bb; }
+        // m: the valid lanes of this wave instruction that hold my digit (me included)
+        const unsigned before = s_cnt[wave][d];               // ... in this wave's earlier instructions (LDS ops of a wave run in order)
+        pre[k] = before + (unsigned)__popcll(m & lt);
+        if (valid && (m & lt) == 0ull) s_cnt[wave][d] = before + (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    {   // thread = digit: the waves' totals -> where each wave's keys of the digit start inside the tile's share
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        if (base + k * 64 + lane >= n) continue;
+        const unsigned d = (unsigned)(key[k] >> shift) & 255u;
+        out[s_base[d] + s_cnt[wave][d] + pre[k]] = key[k];
+    }
+}
+
 // ---- grouping of a global batch (see metrics.hip.h): key = f << 51 | row << 20 | t, invalid rows = 2^31 - 1
 constexpr int G_TB = 20, G_RB = 31;
 constexpr unsigned long long G_INV = (1ull << G_RB) - 1;
@@ -124,16 +216,34 @@ __global__ __launch_bounds__(256) void k_group_rec(const unsigned long long* __r
 
 }  // namespace
 
+void group_records(hipStream_t st, const unsigned long long* sorted, int nseg, int n, int4* rec)
+{
+    const size_t tot = (size_t)nseg * n;
+    hipLaunchKernelGGL(k_group_rec, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sorted, nseg, n, rec);
+}
+
+unsigned long long* radix_sort_segments(hipStream_t st, unsigned long long* keys, unsigned long long* tmp, unsigned* hist, int nseg, int n,
+                                        int lo_bit, int hi_bit)
+{
+    const int nblk = (n + RS_TILE - 1) / RS_TILE;
+    unsigned long long *in = keys, *out = tmp;
+    for (int shift = lo_bit; shift < hi_bit; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk, nseg), dim3(256), 0, st, in, n, shift, nblk, hist);
+        hipLaunchKernelGGL(k_rs_scan, dim3(nseg), dim3(256), 0, st, hist, nblk);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk, nseg), dim3(256), 0, st, in, out, n, shift, nblk, hist);
+        std::swap(in, out);
+    }
+    return in;
+}
+size_t radix_sort_hist_bytes(int nseg, int n) { return (size_t)nseg * 256 * ((n + RS_TILE - 1) / RS_TILE) * sizeof(unsigned); }
+
 int group_global(hipStream_t st, const int32_t* ids, int B, int F, int64_t n_rows, int N2, int4* rec, int* owner_cnt,
                  void** ws, size_t* ws_bytes, std::string& err)
 {
     if (B < 1 || N2 < B || N2 > (1 << G_TB) || F < 1 || F > 64 || n_rows >= (int64_t)G_INV) { err = "group_global: shape out of range"; return -1; }
     const size_t n = (size_t)F * N2;
-    size_t tmp_bytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0,
-                                            G_TB + G_RB + 6, st);
-    if (e != hipSuccess) { err = std::string("rocprim::radix_sort_keys (size query): ") + hipGetErrorString(e); return -1; }
-    const size_t kb = (n * 8 + 255) / 256 * 256, need = 2 * kb + tmp_bytes + 256;
+    hipError_t e;
+    const size_t kb = (n * 8 + 255) / 256 * 256, need = 2 * kb + radix_sort_hist_bytes(F, N2) + 256;
     if (*ws_bytes < need) {
         if (*ws) { hipStreamSynchronize(st); hipFree(*ws); *ws = nullptr; *ws_bytes = 0; }
         e = hipMalloc(ws, need);
@@ -141,12 +251,15 @@ int group_global(hipStream_t st, const int32_t* ids, int B, int F, int64_t n_row
         *ws_bytes = need;
     }
     unsigned long long* keys = static_cast<unsigned long long*>(*ws);
-    unsigned long long* sorted = reinterpret_cast<unsigned long long*>(static_cast<char*>(*ws) + kb);
-    void* tmp = static_cast<char*>(*ws) + 2 * kb;
+    unsigned long long* other = reinterpret_cast<unsigned long long*>(static_cast<char*>(*ws) + kb);
+    unsigned* hist = reinterpret_cast<unsigned*>(static_cast<char*>(*ws) + 2 * kb);
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_group_keys, dim3(nb), dim3(256), 0, st, ids, B, F, n_rows, N2, keys, owner_cnt);
-    e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys, sorted, n, 0, G_TB + G_RB + 6, st);
-    if (e != hipSuccess) { err = std::string("rocprim::radix_sort_keys: ") + hipGetErrorString(e); return -1; }
+    // every field is a segment of N2 keys generated in example order: a stable sort on the row bits alone leaves (row, t) order.
+    // Bits: enough to tell n_rows apart from every valid row -- the all-ones row of an invalid entry then sorts behind them.
+    int rbits = 1;
+    while (((int64_t)1 << rbits) <= n_rows) ++rbits;
+    const unsigned long long* sorted = radix_sort_segments(st, keys, other, hist, F, N2, G_TB, G_TB + rbits);
     hipLaunchKernelGGL(k_group_rec, dim3(nb), dim3(256), 0, st, sorted, F, N2, rec);
     e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("group_global launch: ") + hipGetErrorString(e); return -1; }

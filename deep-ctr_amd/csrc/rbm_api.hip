@@ -12,6 +12,7 @@
 #include "../../include/fnn_hip.h"
 #include "../../include/rbm_hip.h"
 #include "fnn_kernels.hip.h"
+#include "metrics.hip.h"
 
 using namespace fnn;
 
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(256) void k_rbm_sparse32(const SparseArgs a)
 struct BatchArgs {
     const float *W, *visbias, *hidbias, *wstep; float *dW, *dvis; const int32_t* vid; const uint8_t* vval; const float* unif;
     int M, H, S; float wcost, r_vis, r_w, mom; float* part_w; float* part_h; double* part_e;
+    float* hbuf; float* visbuf;       // SORTED form: hid / hid2 of every example [M][2][H] and its reconstructions [M][S] (the row update recomputes the deltas)
 };
 
+template <bool SORTED>
 __global__ __launch_bounds__(256) void k_rbm_batch(const BatchArgs a)
 {
     __shared__ float s_w[32][257];
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(256) void k_rbm_batch(const BatchArgs a)
                 s_vis[j] = vj;
                 const float d = vj - s_v[j];
                 s_e[j] = j < S ? d * d : 0.f;
-                if (j < S) atomicAdd(a.dvis + s_id[j], (s_v[j] - vj) * a.r_vis);
+                if (SORTED) { if (j < S) a.visbuf[(size_t)n * S + j] = vj; }
+                else if (j < S) atomicAdd(a.dvis + s_id[j], (s_v[j] - vj) * a.r_vis);
             }
         }
         __syncthreads();
@@ -262,8 +266,9 @@ __global__ __launch_bounds__(256) void k_rbm_batch(const BatchArgs a)
         for (int j = 0; j < 32; ++j) {
             const float step = ((s_v[j] * hid - s_vis[j] * hid2) - a.wcost * wc[j]) * a.r_w;
             wsum[j] += step;
-            if (act && j < S) atomicAdd(a.dW + (size_t)s_id[j] * H + tid, 2.0f * (ws0[j] + step));
+            if (!SORTED && act && j < S) atomicAdd(a.dW + (size_t)s_id[j] * H + tid, 2.0f * (ws0[j] + step));
         }
+        if (SORTED && act) { a.hbuf[((size_t)n * 2) * H + tid] = hid; a.hbuf[((size_t)n * 2 + 1) * H + tid] = hid2; }
         hacc += hid - hid2;
         if (tid == 0) { float e = 0.f; for (int j = 0; j < 32; ++j) e += s_e[j]; err += (double)e; }
         __syncthreads();
@@ -291,6 +296,137 @@ __global__ __launch_bounds__(256) void k_rbm_apply(float* __restrict__ W, float*
         const float d = atomicExch(dvis + f, 0.f);
         if (d != 0.f) atomicAdd(visbias + f, d);
     }
+}
+
+// ---- the row update of a mini-batch WITHOUT atomics (round 3).  The (row, entry) pairs of the mini-batch -- entry = e * S + j, in
+// example order -- are sorted by row with the library's stable radix sort (metrics.hip: the whole epoch's mini-batches are grouped
+// ahead, a few launches per 16 mini-batches), so a row's entries are one run of `rec`, in example order.  A thread owns a 16-byte
+// quarter-column of a chunk of 32 sorted entries (the A8 update's shape, scatw1_body) and RECOMPUTES every entry's delta from what
+// k_rbm_batch<true> left behind -- hid_e, hid2_e (16 B each), vis_ej, v_ej -- and the positional momentum row:
+//     delta_ej = 2 (momentum wstep[j] + rate_w (v_ej hid_e - vis_ej hid2_e))         (f32, as the atomic form added it)
+//     W[f] <- W[f] (1 - 2 rate_w weightcost m) + sum of the run's deltas              (m = entries of the run; f64 sum, one rounding)
+//     visbias[f] += rate_vis sum (v_ej - vis_ej)
+// Runs inside a chunk are finished by its thread; runs that cross chunks leave partial sums and an owner record, summed in chunk
+// order by k_rbm_scat2.  Fixed order everywhere: two runs give the same bits (the atomic form did not).
+struct RbmScatArgs {
+    const int4* rec; int n;                   // the mini-batch's sorted records, n = M * S slots (invalid ones last)
+    const float* hbuf; const float* visbuf; const uint8_t* vval; const float* wstep;
+    float* W; float* visbias; int H, S; float wcost, r_vis, r_w, mom;
+    double* part; int4* owners; int* owner_cnt;
+};
+constexpr int RCH = 32;                       // sorted entries per chunk
+
+__global__ __launch_bounds__(256) void k_rbm_scat1(const RbmScatArgs a)
+{
+    const int H = a.H, nq = H >> 2, PW = H + 4, nchunk = (a.n + RCH - 1) / RCH;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = (int)(gid / nq), q = (int)(gid % nq);
+    if (chunk >= nchunk) return;
+    const int base = chunk * RCH;
+    const float two_rw = 2.0f * a.r_w, two_mom = 2.0f * a.mom;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, av = 0;
+    int4 rn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rn[j] = base + j < a.n ? a.rec[base + j] : make_int4(-1, 0, 0, 0);
+    for (int sb = 0; sb < RCH; sb += 8) {
+        int4 r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = rn[j];
+        if (r[0].x < 0) break;                               // invalid entries sort to the end
+        if (sb + 8 < RCH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rn[j] = base + sb + 8 + j < a.n ? a.rec[base + sb + 8 + j] : make_int4(-1, 0, 0, 0);
+        }
+        float4 hd[8], h2[8], wsj[8], wold[8]; float v[8], vi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = r[j].x >= 0;
+            const int ent = live ? r[j].y : 0, ex = ent / a.S, slot = ent % a.S;
+            hd[j] = *reinterpret_cast<const float4*>(a.hbuf + ((size_t)ex * 2) * H + 4 * q);
+            h2[j] = *reinterpret_cast<const float4*>(a.hbuf + ((size_t)ex * 2 + 1) * H + 4 * q);
+            wsj[j] = *reinterpret_cast<const float4*>(a.wstep + (size_t)slot * H + 4 * q);
+            v[j] = (float)a.vval[ent]; vi[j] = a.visbuf[ent];
+            // the old row is read only where it is written: at the last entry of a run that lies inside this chunk
+            const int pos = base + sb + j;
+            const bool need = live && pos + 1 == r[j].w && r[j].z >= base;
+            wold[j] = *reinterpret_cast<const float4*>(a.W + (size_t)(need ? r[j].x : 0) * H + 4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (r[j].x < 0) continue;
+            a0 += (double)(two_mom * wsj[j].x + two_rw * (v[j] * hd[j].x - vi[j] * h2[j].x));
+            a1 += (double)(two_mom * wsj[j].y + two_rw * (v[j] * hd[j].y - vi[j] * h2[j].y));
+            a2 += (double)(two_mom * wsj[j].z + two_rw * (v[j] * hd[j].z - vi[j] * h2[j].z));
+            a3 += (double)(two_mom * wsj[j].w + two_rw * (v[j] * hd[j].w - vi[j] * h2[j].w));
+            av += (double)((v[j] - vi[j]) * a.r_vis);
+            const int pos = base + sb + j, s = r[j].z, e = r[j].w;
+            if (pos + 1 != e && pos + 1 != base + RCH) continue;       // the run goes on inside this chunk
+            if (s >= base && e <= base + RCH) {                        // the whole run lies in this chunk
+                const double keep = 1.0 - (double)two_rw * (double)a.wcost * (double)(e - s);
+                *reinterpret_cast<float4*>(a.W + (size_t)r[j].x * H + 4 * q) =
+                    make_float4((float)((double)wold[j].x * keep + a0), (float)((double)wold[j].y * keep + a1),
+                                (float)((double)wold[j].z * keep + a2), (float)((double)wold[j].w * keep + a3));
+                if (q == 0) a.visbias[r[j].x] = (float)((double)a.visbias[r[j].x] + av);
+            } else {
+                const int which = (s < base) ? 0 : 1;
+                double* pp = a.part + ((size_t)chunk * 2 + which) * PW;
+                pp[4 * q] = a0; pp[4 * q + 1] = a1; pp[4 * q + 2] = a2; pp[4 * q + 3] = a3;
+                if (q == 0) { pp[H] = av; if (which == 1) a.owners[atomicAdd(a.owner_cnt, 1)] = make_int4(0, s, e, r[j].x); }
+            }
+            a0 = a1 = a2 = a3 = av = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rbm_scat2(const RbmScatArgs a)
+{
+    __shared__ double s_w[4 * 264];
+    const int H = a.H, nq = H >> 2, PW = H + 4, ngrp = 256 / nq < 4 ? 256 / nq : 4;
+    const int grp = threadIdx.x / nq, q = threadIdx.x % nq;
+    const int n = *a.owner_cnt;
+    for (int o = blockIdx.x; o < n; o += gridDim.x) {
+        const int4 ow = a.owners[o];                         // {0, s, e, row}
+        const int q0 = ow.y / RCH, q1 = (ow.z - 1) / RCH;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, av = 0;
+        float4* p = reinterpret_cast<float4*>(a.W + (size_t)ow.w * H + 4 * q);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp == 0) w = *p;
+        if (grp < ngrp) {
+            for (int qq = q0 + grp; qq <= q1; qq += ngrp) {   // a group takes every ngrp-th chunk of the run, in chunk order
+                const double* pp = a.part + ((size_t)qq * 2 + (qq == q0 ? 1 : 0)) * PW;
+                a0 += pp[4 * q]; a1 += pp[4 * q + 1]; a2 += pp[4 * q + 2]; a3 += pp[4 * q + 3];
+                if (q == 0) av += pp[H];
+            }
+            double* d = s_w + ((size_t)grp * (nq + 1) + q) * 4;
+            d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+            if (q == 0) s_w[((size_t)grp * (nq + 1) + nq) * 4] = av;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            double t0 = 0, t1 = 0, t2 = 0, t3 = 0, tv = 0;
+            for (int gI = 0; gI < ngrp; ++gI) {
+                const double* d = s_w + ((size_t)gI * (nq + 1) + q) * 4;
+                t0 += d[0]; t1 += d[1]; t2 += d[2]; t3 += d[3];
+                if (q == 0) tv += s_w[((size_t)gI * (nq + 1) + nq) * 4];
+            }
+            const double keep = 1.0 - 2.0 * (double)a.r_w * (double)a.wcost * (double)(ow.z - ow.y);
+            *p = make_float4((float)((double)w.x * keep + t0), (float)((double)w.y * keep + t1), (float)((double)w.z * keep + t2),
+                             (float)((double)w.w * keep + t3));
+            if (q == 0) a.visbias[ow.w] = (float)((double)a.visbias[ow.w] + tv);
+        }
+        __syncthreads();
+    }
+}
+
+// keys of `nmb` mini-batches (segments of M * S): row << 20 | (e * S + j), example order; entries of examples past N: invalid
+__global__ __launch_bounds__(256) void k_rbm_keys(const int32_t* __restrict__ vid, int64_t n_entries, int seg_n, int nmb, unsigned long long* __restrict__ keys)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)nmb * seg_n) return;
+    const size_t idx = gid;                                     // mini-batch g = gid / seg_n holds entries [g * seg_n, ...)
+    unsigned long long row = GROUP_INVALID_ROW;
+    if ((int64_t)idx < n_entries) { const int id = vid[idx]; if (id >= 0) row = (unsigned long long)id; }
+    keys[gid] = (row << GROUP_INDEX_BITS) | (unsigned long long)(gid % seg_n);
 }
 
 // 64 elements x 16 groups of workgroup partials per block: a thread sums every 16th partial of its element (eight loads
@@ -561,24 +697,64 @@ int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hi
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
     hipStream_t st = (hipStream_t)stream;
     const int nwg_max = (int)std::min<int64_t>(M, 1024);       // 4 workgroups per CU; more examples than that: several per workgroup
+    // the row update without atomics needs 16-byte quarter-columns (H % 4 == 0) and entry indices that fit the key (M * S <= 2^20);
+    // anything else keeps the atomic form ($RBM_BATCH_ATOMICS=1 forces it: A/B measurements)
+    const char* ev = getenv("RBM_BATCH_ATOMICS");
+    const bool sorted = H % 4 == 0 && (int64_t)M * S <= ((int64_t)1 << GROUP_INDEX_BITS) && !(ev && ev[0] == '1');
     float *part_w = nullptr, *part_h = nullptr; double *part_e = nullptr, *d_err = nullptr;
-    RCK(hipMalloc((void**)&part_w, (size_t)nwg_max * S * H * 4)); RCK(hipMalloc((void**)&part_h, (size_t)nwg_max * H * 4));
-    RCK(hipMalloc((void**)&part_e, (size_t)nwg_max * 8)); RCK(hipMalloc((void**)&d_err, 8));
+    std::vector<void*> owned;
+    auto cleanup = [&]() { for (void* q : owned) if (q) hipFree(q); };
+#define RAL(ptr, bytes) do { void* q_ = nullptr; hipError_t e_ = hipMalloc(&q_, (bytes)); if (e_ != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e_); cleanup(); return FNN_ERR_NOMEM; } owned.push_back(q_); ptr = static_cast<decltype(ptr)>(q_); } while (0)
+    RAL(part_w, (size_t)nwg_max * S * H * 4); RAL(part_h, (size_t)nwg_max * H * 4); RAL(part_e, (size_t)nwg_max * 8); RAL(d_err, 8);
     RCK(hipMemsetAsync(d_err, 0, 8, st));
-    for (int64_t n0 = 0; n0 < N; n0 += M) {
+    const int seg_n = M * S, nchunk = (seg_n + RCH - 1) / RCH, GROUP = 16;
+    float *hbuf = nullptr, *visbuf = nullptr; double* spart = nullptr; int4 *owners = nullptr, *rec = nullptr; int* owner_cnt = nullptr;
+    unsigned long long *keys = nullptr, *keys2 = nullptr; unsigned* hist = nullptr;
+    if (sorted) {
+        RAL(hbuf, (size_t)M * 2 * H * 4); RAL(visbuf, (size_t)seg_n * 4); RAL(spart, (size_t)nchunk * 2 * (H + 4) * 8);
+        RAL(owners, (size_t)nchunk * sizeof(int4)); RAL(owner_cnt, 4);
+        RAL(keys, (size_t)GROUP * seg_n * 8); RAL(keys2, (size_t)GROUP * seg_n * 8); RAL(rec, (size_t)GROUP * seg_n * sizeof(int4));
+        RAL(hist, radix_sort_hist_bytes(GROUP, seg_n));
+    }
+    const int rbits = 31;                                       // the whole row field of the key (ids are int32; the all-ones row of an invalid entry sorts last): 4 passes
+    int64_t mb = 0;
+    for (int64_t n0 = 0; n0 < N; n0 += M, ++mb) {
         const int m = (int)std::min<int64_t>(M, N - n0), nwg = std::min(m, nwg_max);
+        const int4* rec_mb = nullptr;
+        if (sorted) {
+            if (mb % GROUP == 0) {                              // group the next GROUP mini-batches' (row, entry) pairs by row
+                const int nmb = (int)std::min<int64_t>(GROUP, (N - n0 + M - 1) / M);
+                const size_t tot = (size_t)nmb * seg_n;
+                hipLaunchKernelGGL(k_rbm_keys, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, vid + n0 * S, (N - n0) * S, seg_n, nmb, keys);
+                const unsigned long long* srt = radix_sort_segments(st, keys, keys2, hist, nmb, seg_n, GROUP_INDEX_BITS, GROUP_INDEX_BITS + rbits);
+                group_records(st, srt, nmb, seg_n, rec);
+            }
+            rec_mb = rec + (size_t)(mb % GROUP) * seg_n;
+        }
         BatchArgs a{W, visbias, hidbias, wstep, dW, dvis, vid + n0 * S, vval + n0 * S, unif + n0 * H, m, H, S, weightcost, rate_vis, rate_w,
-                    momentum, part_w, part_h, part_e};
-        hipLaunchKernelGGL(k_rbm_batch, dim3(nwg), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
+                    momentum, part_w, part_h, part_e, hbuf, visbuf};
+        if (sorted) {
+            hipLaunchKernelGGL(k_rbm_batch<true>, dim3(nwg), dim3(256), 0, st, a);
+            RCK(hipMemsetAsync(owner_cnt, 0, 4, st));
+            RbmScatArgs sa{rec_mb, seg_n, hbuf, visbuf, vval + n0 * S, wstep, W, visbias, H, S, weightcost, rate_vis, rate_w, momentum,
+                           spart, owners, owner_cnt};
+            const long nthr = (long)nchunk * (H / 4);
+            hipLaunchKernelGGL(k_rbm_scat1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, sa);
+            hipLaunchKernelGGL(k_rbm_scat2, dim3(256), dim3(256), 0, st, sa);
+        } else {
+            hipLaunchKernelGGL(k_rbm_batch<false>, dim3(nwg), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
+        }
         hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 63) / 64)), dim3(1024), 0, st, wstep, hidbias, part_w, part_h,
                            part_e, nwg, m, H, S, momentum, rate_hid, d_err);
     }
-    RCK(hipGetLastError());
+    hipError_t le = hipGetLastError();
     double e = 0;
-    RCK(hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st));
-    RCK(hipStreamSynchronize(st));
-    hipFree(part_w); hipFree(part_h); hipFree(part_e); hipFree(d_err);
+    if (le == hipSuccess) le = hipMemcpyAsync(&e, d_err, sizeof(double), hipMemcpyDeviceToHost, st);
+    if (le == hipSuccess) le = hipStreamSynchronize(st);
+    cleanup();
+#undef RAL
+    if (le != hipSuccess) { g_err = std::string("rbm_sparse_batch: ") + hipGetErrorString(le); return FNN_ERR_HIP; }
     if (sq_err_out) *sq_err_out = e;
     return FNN_OK;
 }

@@ -429,8 +429,9 @@ def test_a_rank_on_the_layer_by_layer_path_pairs_with_fast_peers(built, form, wh
         sh_rows = shadow[0][:, 2]
         assert np.all(np.abs(state[0][1][sh_rows] - rows[sh_rows]).max(axis=1) > 0)
         change = np.abs(ref_rows - rows.astype(np.float32)).max()
-        only0 = np.array(sorted(set(sh_rows) - set(np.unique(ids[cut[1]]))))
-        assert np.abs(state[0][1][only0] - ref_rows[only0]).max() <= 3e-4 * change + 1e-7
+        only0 = np.array(sorted(set(int(v) for v in sh_rows) - set(int(v) for v in np.unique(ids[cut[1]]))), np.int64)
+        if len(only0):                                       # rows no example of rank 1 touched: the full-batch result
+            assert np.abs(state[0][1][only0] - ref_rows[only0]).max() <= 3e-4 * change + 1e-7
 
 
 def test_p2p_missing_peer_fails_loudly_and_leaves_the_weights(built):

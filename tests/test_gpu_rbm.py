@@ -89,7 +89,10 @@ def test_dense_cd1_minibatches_and_bf16(built, tmp_path):
 
 def test_sparse_minibatch_mode(built, tmp_path):
     """rbm_sparse_batch (the throughput mode; not the reference's schedule): with mini-batches of 1 it is the online
-    trainer; with mini-batches of 64 it follows oracle.sparse_cd1_minibatch (float atomics: tolerance on the change)."""
+    trainer; with mini-batches of 64 / 200 it follows oracle.sparse_cd1_minibatch.  Round 3: the row update groups the
+    mini-batch's (row, entry) pairs with the library's own stable radix sort and sums every row's run in example order -- no
+    float atomics, so two runs agree bit for bit (asserted; 200 examples in ONE mini-batch: rows hit ~20 times, runs that
+    cross the 32-entry chunks and go through the second level)."""
     import ctypes as C
     import torch
     from deep_ctr_amd import _capi
@@ -98,10 +101,11 @@ def test_sparse_minibatch_mode(built, tmp_path):
     vid, vval = gbrbm.sparse_inputs(gbrbm.parse_lines(path))
     dev = torch.device('cuda', 0)
     st = torch.cuda.current_stream(dev).cuda_stream
-    for M in (1, 64):
+    again = {}
+    for M in (1, 64, 200, 200):
         rng = np.random.RandomState(5)
         ost = ro.SparseRBMState(x_dim, H, S, rng)
-        W0 = ost.W.copy()
+        W0, vb0 = ost.W.copy(), ost.visbias.copy()
         Wd = torch.as_tensor(ost.W.astype(np.float32)).to(dev); vb = torch.as_tensor(ost.visbias.astype(np.float32)).to(dev)
         hb = torch.as_tensor(ost.hidbias.astype(np.float32)).to(dev)
         ws = torch.zeros((S, H), dtype=torch.float32, device=dev)
@@ -135,6 +139,12 @@ def test_sparse_minibatch_mode(built, tmp_path):
         np.testing.assert_allclose(ws.cpu().numpy(), ost.weightstep, rtol=2e-3, atol=1e-9)
         assert abs(err.value - e_ref) <= 1e-4 * e_ref
         assert not dW.any().item() and not dvis.any().item()          # the scratch accumulators come back zero
+        state = (Wd.cpu().numpy().copy(), vb.cpu().numpy().copy(), hb.cpu().numpy().copy(), ws.cpu().numpy().copy())
+        np.testing.assert_allclose(state[1], ost.visbias, rtol=0, atol=2e-3 * np.abs(ost.visbias - vb0).max() + 1e-9)
+        if M in again:
+            for x, z in zip(again[M], state):
+                assert np.array_equal(x, z)                         # bit-reproducible
+        again[M] = state
 
 
 def test_sparse_needs_32_visibles(built, tmp_path):
