@@ -87,6 +87,7 @@ RBM_SIGNATURES = {
     "rbm_last_error": (C.c_char_p, []),
     "rbm_sparse_epoch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _f, _f, _f, _f, C.POINTER(_d), _vp]),
     "rbm_sparse_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _f, _f, _f, _f, C.POINTER(_d), _vp]),
+    "rbm_sparse_batch_dp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, C.POINTER(_d), _vp]),
     "rbm_dense_create": (_i, [_i, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
     "rbm_dense_destroy": (_i, [_vp]),
     "rbm_dense_set": (_i, [_vp, _vp, _vp, _vp]),

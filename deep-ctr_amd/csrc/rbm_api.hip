@@ -431,9 +431,10 @@ __global__ __launch_bounds__(256) void k_rbm_keys(const int32_t* __restrict__ vi
 
 // 64 elements x 16 groups of workgroup partials per block: a thread sums every 16th partial of its element (eight loads
 // in flight at a time), the 16 group sums meet in LDS in a fixed order (deterministic).
+// sums_out != null (data parallelism): the sums leave unapplied, the caller all-reduces them and k_rbm_tail_apply does the rest
 __global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ part_w,
                                                          const float* __restrict__ part_h, const double* __restrict__ part_e, int nwg, int M,
-                                                         int H, int S, float mom, float r_hid, double* __restrict__ err_acc)
+                                                         int H, int S, float mom, float r_hid, double* __restrict__ err_acc, float* __restrict__ sums_out)
 {
     __shared__ float s_p[16][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -456,7 +457,8 @@ __global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wst
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += s_p[g][el];
-        if (i < nW) wstep[i] = mom * wstep[i] + t / (float)M;
+        if (sums_out) sums_out[i] = t;
+        else if (i < nW) wstep[i] = mom * wstep[i] + t / (float)M;
         else hidbias[i - nW] += r_hid * t;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -464,6 +466,15 @@ __global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wst
         for (int w = 0; w < nwg; ++w) e += part_e[w];
         *err_acc += e;
     }
+}
+
+__global__ void k_rbm_tail_apply(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ sums, int nW, int H, int M,
+                                 float mom, float r_hid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nW + H) return;
+    if (i < nW) wstep[i] = mom * wstep[i] + sums[i] / (float)M;
+    else hidbias[i - nW] += r_hid * sums[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,12 +698,13 @@ int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep, con
     return FNN_OK;
 }
 
-int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep, const int32_t* vid,
-                     const uint8_t* vval, const float* unif, int64_t N, int M, int H, int S, float weightcost, float rate_vis,
-                     float rate_hid, float rate_w, float momentum, double* sq_err_out, void* stream)
+static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep, const int32_t* vid,
+                             const uint8_t* vval, const float* unif, int64_t N, int M, int M_global, int H, int S, float weightcost, float rate_vis,
+                             float rate_hid, float rate_w, float momentum, rbm_allreduce_fn allreduce, void* ctx, double* sq_err_out, void* stream)
 {
     if (!W || !dW || !visbias || !dvis || !hidbias || !wstep || !vid || !vval || !unif) RFAIL(FNN_ERR_ARG, "null pointer");
     if (H < 1 || H > 256 || S < 1 || S > 32 || N < 1 || M < 1) RFAIL(FNN_ERR_ARG, "need 1 <= H <= 256, 1 <= S <= 32, N >= 1, M >= 1");
+    if (allreduce && M_global < M) RFAIL(FNN_ERR_ARG, "M_global must be the GLOBAL mini-batch length (>= M)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
     hipStream_t st = (hipStream_t)stream;
@@ -706,6 +718,8 @@ int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hi
     auto cleanup = [&]() { for (void* q : owned) if (q) hipFree(q); };
 #define RAL(ptr, bytes) do { void* q_ = nullptr; hipError_t e_ = hipMalloc(&q_, (bytes)); if (e_ != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e_); cleanup(); return FNN_ERR_NOMEM; } owned.push_back(q_); ptr = static_cast<decltype(ptr)>(q_); } while (0)
     RAL(part_w, (size_t)nwg_max * S * H * 4); RAL(part_h, (size_t)nwg_max * H * 4); RAL(part_e, (size_t)nwg_max * 8); RAL(d_err, 8);
+    float* sums = nullptr;
+    if (allreduce) RAL(sums, (size_t)(S * H + H) * 4);
     RCK(hipMemsetAsync(d_err, 0, 8, st));
     const int seg_n = M * S, nchunk = (seg_n + RCH - 1) / RCH, GROUP = 16;
     float *hbuf = nullptr, *visbuf = nullptr; double* spart = nullptr; int4 *owners = nullptr, *rec = nullptr; int* owner_cnt = nullptr;
@@ -746,7 +760,15 @@ int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hi
             hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
         }
         hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 63) / 64)), dim3(1024), 0, st, wstep, hidbias, part_w, part_h,
-                           part_e, nwg, m, H, S, momentum, rate_hid, d_err);
+                           part_e, nwg, m, H, S, momentum, rate_hid, d_err, sums);
+        if (allreduce) {
+            // every rank runs the same number of mini-batches (its shard of each): the global count is what the mean divides by.
+            // A short LAST mini-batch: the caller passes shards of the same global tail, so the ratio m / M carries over
+            if (allreduce(ctx, sums, (int64_t)(S * H + H), (void*)st) != 0) { cleanup(); RFAIL(FNN_ERR_HIP, "rbm_sparse_batch_dp: the all-reduce callback failed"); }
+            const int mg = (int)((int64_t)M_global * m / M);
+            hipLaunchKernelGGL(k_rbm_tail_apply, dim3((unsigned)((S * H + H + 255) / 256)), dim3(256), 0, st, wstep, hidbias, sums, S * H, H, mg > 0 ? mg : 1,
+                               momentum, rate_hid);
+        }
     }
     hipError_t le = hipGetLastError();
     double e = 0;
@@ -757,6 +779,23 @@ int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hi
     if (le != hipSuccess) { g_err = std::string("rbm_sparse_batch: ") + hipGetErrorString(le); return FNN_ERR_HIP; }
     if (sq_err_out) *sq_err_out = e;
     return FNN_OK;
+}
+
+int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep, const int32_t* vid,
+                     const uint8_t* vval, const float* unif, int64_t N, int M, int H, int S, float weightcost, float rate_vis,
+                     float rate_hid, float rate_w, float momentum, double* sq_err_out, void* stream)
+{
+    return sparse_batch_impl(W, dW, visbias, dvis, hidbias, wstep, vid, vval, unif, N, M, M, H, S, weightcost, rate_vis, rate_hid, rate_w, momentum,
+                             nullptr, nullptr, sq_err_out, stream);
+}
+
+int rbm_sparse_batch_dp(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep, const int32_t* vid,
+                        const uint8_t* vval, const float* unif, int64_t N, int M, int M_global, int H, int S, float weightcost, float rate_vis,
+                        float rate_hid, float rate_w, float momentum, rbm_allreduce_fn allreduce, void* ctx, double* sq_err_out, void* stream)
+{
+    if (!allreduce) RFAIL(FNN_ERR_ARG, "rbm_sparse_batch_dp: null all-reduce callback");
+    return sparse_batch_impl(W, dW, visbias, dvis, hidbias, wstep, vid, vval, unif, N, M, M_global, H, S, weightcost, rate_vis, rate_hid, rate_w,
+                             momentum, allreduce, ctx, sq_err_out, stream);
 }
 
 int rbm_dense_create(int nvis, int nhid, int max_n, int precision, int device, void* stream, rbm_handle** out)

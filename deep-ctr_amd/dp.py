@@ -178,3 +178,54 @@ class _Null(object):
 
     def __exit__(self, *a):
         return False
+
+
+class DataParallelSparseRBM(object):
+    """The mini-batch sparse CD-1 pre-trainer (rbm_sparse_batch; the throughput mode of SURVEY 8d config 5, NOT the reference's
+    online schedule) sharded over the ranks of a process group: every rank holds its contiguous shard of every global mini-batch
+    and the table replicated; per mini-batch ONE all-reduce of S*H + H floats (the positional steps and the hidden-bias terms)
+    keeps wstep / hidbias identical on every rank, while each rank applies the row updates of its own examples (rows several ranks
+    touch drift apart, as in the FNN step's LOCAL mode).  The SNN fine-tune step shards through DataParallelFNN with a bag-mode
+    engine (the native step carries the bag-bias gradient in its slabs / bucket); the online trainer is sequential: replicas only.
+    `allreduce(view)`: sums a float32 tensor view in place over the ranks (default: torch.distributed.all_reduce on `group`)."""
+
+    def __init__(self, group=None, allreduce=None, device=0):
+        import torch
+        from . import _capi
+        self.torch, self.lib, self.C = torch, _capi.load(), __import__('ctypes')
+        self.device = torch.device('cuda', device)
+        if allreduce is None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+
+            def allreduce(view):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        self._allreduce = allreduce
+        from .engine import _tensor_from_ptr
+        C = self.C
+
+        def _cb(ctx, buf, n, stream):
+            try:
+                self.torch.cuda.current_stream(self.device).synchronize()      # the sums are complete before a host-staged collective reads them
+                self._allreduce(_tensor_from_ptr(self.torch, buf, n, self.device))
+                self.torch.cuda.current_stream(self.device).synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(_cb)
+
+    def epoch(self, W, dW, visbias, dvis, hidbias, wstep, vid, vval, unif, M_local, M_global, weightcost=2e-4, rate=1e-4, momentum=0.9):
+        """One pass over this rank's examples (device tensors, shapes as rbm_sparse_batch takes them); returns this rank's squared error."""
+        C = self.C
+        N, S = vid.shape
+        H = W.shape[1]
+        err = C.c_double()
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.rbm_sparse_batch_dp(W.data_ptr(), dW.data_ptr(), visbias.data_ptr(), dvis.data_ptr(), hidbias.data_ptr(), wstep.data_ptr(),
+                                          vid.data_ptr(), vval.data_ptr(), unif.data_ptr(), N, int(M_local), int(M_global), H, S, weightcost, rate, rate,
+                                          rate, momentum, C.cast(self._cb, C.c_void_p), None, C.byref(err), st)
+        if rc != 0:
+            raise RuntimeError((self.lib.rbm_last_error() or b'').decode())
+        return err.value

@@ -48,12 +48,28 @@ int rbm_sparse_epoch(float* W, float* visbias, float* hidbias, float* wstep,
  * mini-batches of M; every example of a mini-batch reads the parameters as they were at its start:
  *     step_e[j] as in :447-453;  W[f_ej] += 2 (momentum wstep[j] + step_e[j]);  wstep[j] = momentum wstep[j] + mean_e step_e[j];
  *     visbias[f_ej] += (v_ej - vis_ej) rate_vis;  hidbias += rate_hid sum_e (hid_e - hid2_e).
- * dW [n_vis, H] and dvis [n_vis] are scratch accumulators owned by the caller: all zero on entry, all zero on return.
- * Row sums are accumulated with float atomics: results are reproducible only up to the rounding of those sums. */
+ * dW [n_vis, H] and dvis [n_vis] are scratch accumulators owned by the caller: all zero on entry, all zero on return (used by
+ * the fallback below only).  Round 3: the row update sorts the mini-batch's (row, entry) pairs by row (the library's own stable
+ * radix sort, a whole group of mini-batches ahead) and sums every row's run in example order, recomputing the deltas from the
+ * examples' hid / hid2 / vis -- no float atomics, bit-reproducible.  H % 4 != 0 (or RBM_BATCH_ATOMICS=1) keeps the round-2 form:
+ * row sums accumulated with float atomics, reproducible only up to the rounding of those sums. */
 int rbm_sparse_batch(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep,
                      const int32_t* vid, const uint8_t* vval, const float* unif,
                      int64_t N, int M, int H, int S, float weightcost, float rate_vis, float rate_hid,
                      float rate_w, float momentum, double* sq_err_out, void* stream);
+
+/* Data-parallel form of rbm_sparse_batch (new: the reference is one process; SURVEY 8e "batched mode shards like A8").  Every rank
+ * holds its contiguous shard of every GLOBAL mini-batch: N and M count THIS rank's examples, M_global the whole mini-batch.  Per
+ * mini-batch the ranks' sums of the positional steps and of the hidden-bias terms -- one flat buffer of S * H + H floats -- are summed
+ * over the ranks by `allreduce` (in place, enqueued on `stream` or completed before it returns; 0 = OK), so wstep and hidbias stay
+ * identical on every rank (wstep[j] = momentum wstep[j] + sum / M_global).  Each rank applies the row updates (W, visbias) of its own
+ * examples only: tables are replicated and rows that several ranks touch drift apart, as in FNN_DP_SPARSE_LOCAL.  sq_err_out is this
+ * rank's share.  The online trainer (rbm_sparse_epoch) is sequential by definition and has no data-parallel form: replicas only. */
+typedef int (*rbm_allreduce_fn)(void* ctx, float* buf, int64_t n_floats, void* stream);
+int rbm_sparse_batch_dp(float* W, float* dW, float* visbias, float* dvis, float* hidbias, float* wstep,
+                        const int32_t* vid, const uint8_t* vval, const float* unif,
+                        int64_t N, int M, int M_global, int H, int S, float weightcost, float rate_vis, float rate_hid,
+                        float rate_w, float momentum, rbm_allreduce_fn allreduce, void* ctx, double* sq_err_out, void* stream);
 
 /* Dense CD-1 (RBM + CDTrainer).  The handle owns the parameters [W | visbias | hidbias]
  * (python :13-26), the momentum buffer (:166) and the work buffers for up to max_n rows. */

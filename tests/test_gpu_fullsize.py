@@ -66,17 +66,69 @@ def test_ipnn_l7_step_bf16_on_the_full_table(built):
     t0 = tc.copy()
     p0 = [w.copy() for w in params['W']]
     loss, logits, g = io.sgd_step(params, tc, idc, y, 'relu', 1e-3, [m.astype(np.float64) for m in masks], 0.5)
-    assert np.abs(out['logits'].cpu().numpy() - logits).max() < 5e-2
-    assert abs(out['loss'] - loss) <= 2e-2 * abs(loss)
+    obs = {'logits_max_abs_err': float(np.abs(out['logits'].cpu().numpy() - logits).max()), 'loss_rel_err': float(abs(out['loss'] - loss) / abs(loss))}
     b, Ws, bs = eng.get_params()
+    cosines = []
     for t in range(len(Ws)):
         du, dv = (Ws[t] - p0[t]).ravel(), (params['W'][t] - p0[t]).ravel()
-        cos = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
-        assert cos > 0.98, (t, cos)
+        cosines.append(float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30)))
     got = eng.get_rows(touched).astype(np.float64)
     du, dv = (got - t0).ravel(), (tc - t0).ravel()
-    assert float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30)) > 0.98
-    assert np.abs(got - tc).max() <= 8e-2 * np.abs(tc - t0).max() + 1e-6
+    obs['dense_update_cosines'] = cosines
+    obs['row_update_cosine'] = float(du @ dv / (np.linalg.norm(du) * np.linalg.norm(dv) + 1e-30))
+    obs['row_err_over_largest_update'] = float(np.abs(got - tc).max() / np.abs(tc - t0).max())
+    try:                                                    # kept beside the profiles (DESIGN.md quotes them)
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        json.dump(obs, open(os.path.join(root, 'gpurun_out', 'ipnn_fullsize_bf16_observed.json'), 'w'))
+    except OSError:
+        pass
+    # observed on MI355X (profiles/r03_ipnn_fullsize_bf16_observed.json); asserted at about twice that.  The tight anchor of this
+    # shape is the f32 test below.
+    assert obs['logits_max_abs_err'] < 5e-2 and obs['loss_rel_err'] <= 2e-2
+    assert min(cosines) > 0.98, cosines
+    assert obs['row_update_cosine'] > 0.98 and obs['row_err_over_largest_update'] <= 8e-2
+    un = untouched_sample(touched)
+    assert np.array_equal(eng.get_rows(un), table[un])
+    eng.close()
+
+
+def test_ipnn_l7_step_f32_on_the_full_table(built):
+    """The tight anchor of BASELINE configs[2] at its full shape: the same problem in the f32 mode (exact-f32 MFMA), held to the
+    tolerances of tests/test_gpu_ipnn.py::test_ipnn_step_f32_vs_oracle -- logits rtol 2e-4, the loss to 5e-5, every dense
+    tensor's and every touched row's UPDATE within 2e-3 of its size, untouched rows bit for bit.  (Round-2 review: the bf16 test
+    above is loose by necessity -- seven bf16 layers -- and nothing tight stood behind this shape.)"""
+    hidden = [1000, 800, 600, 400, 200, 100, 50]
+    B = 4096
+    rng = np.random.RandomState(11)
+    table = synth.fm_table(D, K, 0.2, 1234)
+    ids = synth.zipf_ids(B, SIZES, 1.1, 77)
+    y = (rng.uniform(size=B) < 0.3).astype(np.float64)
+    d = [F * K + F * (F - 1) // 2 + 1] + hidden + [1]
+    params = {'b': float(np.float32(0.1)), 'W': [f32r(rng.uniform(-0.06, 0.06, (d[i], d[i + 1]))) for i in range(len(d) - 1)],
+              'bias': [f32r(rng.uniform(-0.1, 0.1, d[i + 1])) for i in range(len(d) - 1)]}
+    masks = [(np.random.RandomState(40 + t).uniform(size=(B, d[t])) < 0.5).astype(np.uint8) for t in range(len(hidden) + 1)]
+    eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='f32', lr=1e-3, keep_prob=0.5)
+    eng.set_params(table, params['b'], params['W'], params['bias'])
+    out = eng.train_step(ids, y, masks, want_logits=True)
+    touched, idc = compact(ids)
+    tc = table[touched].astype(np.float64)
+    t0 = tc.copy()
+    p0 = {'b': params['b'], 'W': [w.copy() for w in params['W']], 'bias': [b.copy() for b in params['bias']]}
+    loss, logits, g = io.sgd_step(params, tc, idc, y, 'relu', 1e-3, [m.astype(np.float64) for m in masks], 0.5)
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), logits, rtol=2e-4, atol=2e-5)
+    assert abs(out['loss'] - loss) <= 5e-5 * max(1.0, abs(loss))
+    b, Ws, bs = eng.get_params()
+    for t in range(len(Ws)):
+        cw = np.abs(params['W'][t] - p0['W'][t]).max() + 1e-12
+        assert np.abs(Ws[t] - params['W'][t]).max() <= 2e-3 * cw + 2e-7, ('W', t)
+        cb = np.abs(params['bias'][t] - p0['bias'][t]).max() + 1e-12
+        assert np.abs(bs[t] - params['bias'][t]).max() <= 2e-3 * cb + 2e-7, ('b', t)
+    assert abs(b - params['b']) <= 2e-3 * abs(params['b'] - p0['b']) + 2e-7
+    ct = np.abs(tc - t0).max() + 1e-12
+    assert np.abs(eng.get_rows(touched) - tc).max() <= 2e-3 * ct + 2e-7
     un = untouched_sample(touched)
     assert np.array_equal(eng.get_rows(un), table[un])
     eng.close()

@@ -581,6 +581,33 @@ def test_full_shape_step_f32_vs_oracle(built, full_problem):
     eng.close()
 
 
+def test_full_shape_step_bf16_vs_oracle(built, full_problem):
+    """The HEADLINE precision at the headline shape (BASELINE configs[1]: 937,670 rows, batch 4096, bf16) against the float64
+    oracle, at the tolerances of test_train_step_bf16_vs_oracle: p_drop within 2e-2, gx within 5 % of its scale, the loss within
+    2 %, every touched row within 5 % of the largest row update, untouched rows bit for bit (round-2 review: this shape had
+    property checks only in bf16)."""
+    rows, fo, ids, y, p, r1, r2 = full_problem
+    eng = make_engine(rows, fo, p, prec='bf16', lr=0.001)
+    out = eng.train_step(ids, y, r1, r2, want_p=True, want_gx=True)
+    rows64 = rows.astype(np.float64)
+    p64 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    ref = orc.train_step(p64, rows64, -3.0, ids, y.astype(np.float64), r1.astype(float), r2.astype(float), 0.001, 0.0, 0.1)
+    assert np.abs(out['p'].cpu().numpy() - ref['p_drop']).max() < 2e-2
+    gs = np.abs(ref['gx']).max()
+    assert np.abs(out['gx'].cpu().numpy() - ref['gx']).max() < 5e-2 * gs
+    assert abs(out['loss'] - ref['loss']) < 2e-2 * ref['loss']
+    touched = np.unique(ids)
+    upd = np.abs(rows64[touched] - rows[touched].astype(np.float64)).max()
+    assert np.abs(eng.get_rows(touched) - rows64[touched]).max() < 5e-2 * upd + 1e-6
+    d = eng.get_dense()
+    for k in ('w1', 'b1', 'w2', 'b2', 'w3'):                    # the dense SGD step: each tensor's update within 5 % of its size
+        scale = np.abs(p64[k] - p[k]).max() + 1e-12
+        assert np.abs(d[k] - p64[k]).max() <= 5e-2 * scale + 1e-7, k
+    un = np.setdiff1d(np.random.RandomState(3).randint(0, rows.shape[0], 20000), touched)
+    assert np.array_equal(eng.get_rows(un), rows[un])
+    eng.close()
+
+
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
 def test_full_shape_properties(built, full_problem, prec):
     """Size-independent properties at the full shape:

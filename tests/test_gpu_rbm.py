@@ -197,3 +197,83 @@ def test_snn_rbm_script_on_demo_tracks_oracle(built, golden_dir, tmp_path, monke
         print("SNN demo: auc %.6f vs %.6f, logloss %.6f vs %.6f" % (hrec['test_auc'], auc, hrec['test_logloss'], ll))
         assert abs(hrec['test_auc'] - auc) <= 2e-3
         assert abs(hrec['test_logloss'] - ll) <= 2e-4
+
+
+def test_sparse_minibatch_data_parallel_two_virtual_ranks(built, tmp_path):
+    """rbm_sparse_batch_dp / dp.DataParallelSparseRBM: every rank holds its shard of every global mini-batch; ONE all-reduce of
+    S*H + H floats per mini-batch keeps wstep and hidbias identical on the ranks.  Two virtual ranks (two host threads, an
+    all-reduce that meets at a barrier) against ONE process running the global mini-batches: after one global mini-batch the
+    positional steps and the hidden bias agree with the single run and are bit-identical across the ranks; a row only one
+    rank's examples touch equals the single run's row; after three mini-batches the ranks still hold identical wstep / hidbias."""
+    import ctypes as C
+    import threading
+    import torch
+    from deep_ctr_amd import _capi
+    from deep_ctr_amd.dp import DataParallelSparseRBM
+    path, lines_feats, x_dim = make_lines(tmp_path, n=200)
+    lib, H, S, Mg = _capi.load(), 40, 32, 64
+    vid, vval = gbrbm.sparse_inputs(gbrbm.parse_lines(path))
+    dev = torch.device('cuda', 0)
+    rng = np.random.RandomState(5)
+    ost = ro.SparseRBMState(x_dim, H, S, rng)
+    unif = rng.uniform(size=(len(lines_feats), H)).astype(np.float32)
+
+    def fresh():
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)      # noqa: E731
+        W, vb, hb = t(ost.W), t(ost.visbias), t(ost.hidbias)
+        return W, torch.zeros_like(W), vb, torch.zeros_like(vb), hb, torch.zeros((S, H), dtype=torch.float32, device=dev)
+
+    for nmb in (1, 3):
+        N = nmb * Mg
+        # one process, global mini-batches
+        W, dW, vb, dvis, hb, ws = fresh()
+        vd, vv, ud = (torch.as_tensor(a[:N]).to(dev).contiguous() for a in (vid, vval, unif))
+        err = C.c_double()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        assert lib.rbm_sparse_batch(W.data_ptr(), dW.data_ptr(), vb.data_ptr(), dvis.data_ptr(), hb.data_ptr(), ws.data_ptr(), vd.data_ptr(),
+                                    vv.data_ptr(), ud.data_ptr(), N, Mg, H, S, 2e-4, 1e-4, 1e-4, 1e-4, 0.9, C.byref(err), st) == 0
+        torch.cuda.synchronize()
+        # two ranks, 32 examples of every mini-batch each
+        bar, views = threading.Barrier(2), [None, None]
+
+        def allreduce_for(r):
+            def fn(view):
+                views[r] = view
+                bar.wait()
+                tot = views[0] + views[1]
+                torch.cuda.synchronize()
+                bar.wait()
+                view.copy_(tot)
+                torch.cuda.synchronize()
+                bar.wait()
+            return fn
+        sel = [np.concatenate([np.arange(b * Mg + r * 32, b * Mg + r * 32 + 32) for b in range(nmb)]) for r in (0, 1)]
+        states, errs, fails = [fresh(), fresh()], [0.0, 0.0], []
+
+        def go(r):
+            try:
+                d = DataParallelSparseRBM(allreduce=allreduce_for(r))
+                Wr, dWr, vbr, dvr, hbr, wsr = states[r]
+                a = [torch.as_tensor(x[sel[r]]).to(dev).contiguous() for x in (vid, vval, unif)]
+                errs[r] = d.epoch(Wr, dWr, vbr, dvr, hbr, wsr, a[0], a[1], a[2], 32, Mg)
+            except BaseException as e:       # noqa: B902
+                fails.append(e); bar.abort()
+        ths = [threading.Thread(target=go, args=(r,)) for r in (0, 1)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not fails, fails
+        torch.cuda.synchronize()
+        (W0, _, vb0, _, hb0, ws0), (W1, _, vb1, _, hb1, ws1) = states
+        assert torch.equal(ws0, ws1) and torch.equal(hb0, hb1)             # every rank applied the same sums
+        if nmb == 1:
+            np.testing.assert_allclose(ws0.cpu().numpy(), ws.cpu().numpy(), rtol=1e-4, atol=1e-10)
+            np.testing.assert_allclose(hb0.cpu().numpy(), hb.cpu().numpy(), rtol=1e-6, atol=1e-9)
+            assert abs(errs[0] + errs[1] - err.value) <= 1e-6 * err.value
+            rows = [set(np.unique(vid[s])) for s in sel]
+            only0 = np.array(sorted(rows[0] - rows[1]), np.int64)
+            assert len(only0) > 0
+            np.testing.assert_allclose(W0.cpu().numpy()[only0], W.cpu().numpy()[only0], rtol=1e-6, atol=1e-9)
+            only1 = np.array(sorted(rows[1] - rows[0]), np.int64)
+            assert torch.equal(W0[only1], torch.as_tensor(ost.W.astype(np.float32)).to(dev)[only1])    # rank 0 never moved them
