@@ -373,6 +373,10 @@ template <typename T> struct StripFwdArgs {
     int rot;                                                     // rotate the block order per workgroup (IPNN_STRIP_ROT=0: off)
     StripDuo duo;                                                // two workgroups per strip (see StripDuo); duo.on = 0: one
     int sel;                                                     // IPNN_STAMPS: the product whose first block of wave 0 is stamped in detail (slots 10..14)
+    // A launch may cover a RANGE of the stack (round 3: the wide products as pairs of 32-example strips, the narrow tail as 16-example
+    // strips on every CU).  has_out = 0: the last product of this launch is a hidden layer whose tile leaves for HBM in the F layout
+    // (finalF: the next launch's a0), block by block as it is computed -- no swap, no barrier behind it.
+    int has_out; T* finalF;
 };
 template <typename T> struct StripBwdArgs {
     const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
@@ -381,6 +385,9 @@ template <typename T> struct StripBwdArgs {
     long long* dbg;
     int rot;
     StripDuo duo;
+    // bottom = 1: product 1 of this launch is the stack's first (its output is dz1, f32, no tile).  bottom = 0: the launch stops inside
+    // the stack and product 1's tile leaves for HBM in the F layout (finalF: the next launch's dlast)
+    int bottom; T* finalF;
 };
 
 // one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
@@ -553,6 +560,21 @@ __device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const 
         __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (int)(dst + m * 2048 + (lane + 64) * 16), 0, 16);
     }
 }
+// block j of the tile `out`, just written by this wave, to its place in an F-layout operand in HBM (plain 16-byte stores; the
+// strip's row tiles are contiguous there, so the tile's own offsets apply): the hand-over between two launches of a split stack
+template <typename T, int RT>
+__device__ __forceinline__ void strip_final_push(T* __restrict__ dstF, const T* out, const int N, const int sidx, const int j, const int lane)
+{
+    T* base = dstF + (size_t)sidx * RT * 16 * N;
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        const size_t o = ft_off<T>(m * 16, j * 64, N);
+        const duo_u32x4* src = reinterpret_cast<const duo_u32x4*>(out + o);
+        duo_u32x4* dst = reinterpret_cast<duo_u32x4*>(base + o);
+        const duo_u32x4 v0 = src[lane], v1 = src[lane + 64];
+        dst[lane] = v0; dst[lane + 64] = v1;
+    }
+}
 // every wave has drained its pushes -> flag -> the partner's flag -> the partner's blocks into `out`.  `pull` = false: this
 // workgroup has nothing left to compute (it only publishes).  All 64 NW threads call it.
 template <typename T, int RT>
@@ -632,7 +654,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     int seq = 0;
     for (int l = 0; l <= last; ++l) {
         const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
-        const bool hidden = l + 1 < a.n;
+        const bool hidden = !a.has_out || l + 1 < a.n;
+        const bool fin = !a.has_out && l + 1 == a.n;            // the launch stops here: blocks go to HBM, nobody swaps
         bool split; int cnt; blocks(l, split, cnt);
         while (nx.p == l) {
             const int blk = strip_phys(split, nx.blk, cnt, h, rot);
@@ -651,7 +674,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 DET(12);
                 strip_epilogue<T, RT>(acc, ax, ef, out, N, row0, blk, lane);
                 DET(13);
-                if (split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+                if (fin) { if (split || h == 0) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane); }
+                else if (split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
             } else {                                              // the output unit: logits, loss, delta (column 0)
                 strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 nx.p = a.n;
@@ -672,8 +696,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 }
             }
         }
-        if (split) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
-        if (hidden) lds_barrier();
+        if (split && !fin) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
+        if (hidden && !fin) lds_barrier();
         STRIP_STAMP(2 + l);
         T* t = in; in = out; out = t;
     }
@@ -719,8 +743,9 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
             strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
             nx = strip_next(a, nx, wave, false, h);
             prefetch_next();
-            strip_epilogue<T, RT>(acc, ax, eb, t > 1 ? out : nullptr, N, row0, blk, lane);
+            strip_epilogue<T, RT>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
             if (split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+            if (t == 1 && !a.bottom && (split || h == 0)) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane);
         }
         if (split && t > 1) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (t > 1) lds_barrier();
@@ -974,6 +999,7 @@ struct ipnn_handle {
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
+    int tail_split = 1;                              // IPNN_TAIL_SPLIT=0: the whole stack in one strip launch per direction (round 2's form)
     bool duo_failed = false;                         // a pair gave up once: every later train step is refused until the handle is re-created
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_ev;
@@ -1095,9 +1121,23 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             h->strip_attr = true;
         }
     }
+    // Round 3: the narrow tail of the stack in launches of its own.  The products a pair does not split (fewer than duo_min column
+    // blocks: 448 -> 256 -> 128 -> 64 -> 1 of FNN_IP_L7) are a chain of short k-loops, each a barrier, an epilogue and a cold weight
+    // fetch long -- stamped at 4.5-7 us per product, 23 us forward and 29 us backward for 4 % of the FLOPs, on HALF the CUs forward
+    // (the second workgroup of a pair has nothing to do there).  They run as 16-example strips instead: 256 workgroups, one per CU, no
+    // pairs; the wide products keep the pairs of 32-example strips.  The hand-over is the tile of layer `cut` in the F layout (a[cut]
+    // forward, dl[cut - 1] backward), written block by block by the waves that computed it.
+    int cut = L;
+    while (cut >= 1 && h->Dp[cut] / 64 < h->duo_min) --cut;
+    const bool tsplit = strip && duo && h->tail_split && cut >= 1 && cut < L;
+    int maxD2 = 0;
+    for (int t = cut; t <= L + 1; ++t) maxD2 = std::max(maxD2, h->Dp[t]);
+    const size_t tail_lds = (size_t)2 * 16 * maxD2 * sizeof(T);
     if (strip) {
         IpProf ps(h, "fwd");
         StripFwdArgs<T> sa{};
@@ -1110,8 +1150,24 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         sa.dbg = h->stamps; sa.rot = h->strip_rot; sa.sel = getenv("IPNN_STAMP_SEL") ? atoi(getenv("IPNN_STAMP_SEL")) : -1;
-        sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
-        hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
+        sa.has_out = 1; sa.finalF = nullptr;
+        if (!tsplit) {
+            sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
+        } else {
+            StripFwdArgs<T> s1 = sa;                                  // products 1 .. cut: pairs of 32-example strips; a[cut] -> HBM
+            s1.n = cut; s1.has_out = 0; s1.finalF = (T*)h->a[cut];
+            s1.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
+            StripFwdArgs<T> s2{};                                     // products cut + 1 .. L + 1: 16-example strips, every CU
+            s2.a0 = (const T*)h->a[cut]; s2.n = L + 1 - cut;
+            for (int t = cut; t <= L + 1; ++t) s2.Dp[t - cut] = h->Dp[t];
+            for (int t = cut + 1; t <= L + 1; ++t) s2.W[t - cut - 1] = sa.W[t - 1];
+            for (int t = cut + 1; t <= L; ++t) s2.ef[t - cut - 1] = sa.ef[t - 1];
+            s2.eo = sa.eo; s2.dbg = nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr;
+            s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds, h->st, s2, maxD2);
+        }
     } else {
     IpProf ps(h, "fwd");
     for (int t = 1; t <= L; ++t) {       // l_t = a_{t-1} W_t ; a_t = drop(act(l_t))
@@ -1139,8 +1195,23 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        first ? h->ref0 : nullptr};
         }
         sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
-        sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
-        hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
+        sb.bottom = 1; sb.finalF = nullptr;
+        if (!tsplit) {
+            sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
+        } else {
+            StripBwdArgs<T> sA{};                                     // products L + 1 .. cut + 1 (the narrow ones come first): 16-example strips
+            sA.dlast = (const T*)h->dl[L]; sA.n = L + 1 - cut;
+            for (int t = cut; t <= L + 1; ++t) sA.Dp[t - cut] = h->Dp[t];
+            for (int t = cut + 1; t <= L + 1; ++t) { sA.W[t - cut - 1] = sb.W[t - 1]; sA.eb[t - cut - 1] = sb.eb[t - 1]; }
+            sA.dbg = nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1];
+            sA.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds, h->st, sA, maxD2);
+            StripBwdArgs<T> sB = sb;                                  // products cut .. 1: pairs of 32-example strips, from delta l_cut in HBM
+            sB.dlast = (const T*)h->dl[cut - 1]; sB.n = cut;
+            sB.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, sB, maxD);
+        }
     } else {
     IpProf ps(h, "bwd");
     for (int t = L + 1; t >= 1; --t) {   // delta l_{t-1} from delta l_t ; then gW_t = a_{t-1}^T delta l_t
@@ -1265,6 +1336,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_STRIP")) h->strip = atoi(e) != 0;
     if (const char* e = getenv("IPNN_STRIP_DUO")) h->duo = atoi(e);
     if (const char* e = getenv("IPNN_DUO_MIN")) h->duo_min = std::max(2, atoi(e));
+    if (const char* e = getenv("IPNN_TAIL_SPLIT")) h->tail_split = atoi(e);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
