@@ -11,6 +11,7 @@
 //                 sums (x W, d W) are a 16-partial LDS reduction; four barriers per example.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/dae_hip.h"
@@ -207,6 +208,149 @@ __global__ __launch_bounds__(1024) void k_dae_dense_g(const DenseGArgs<S> a)
     if (l == 0) s_cost[w] = cost;
     __syncthreads();
     if (tid == 0 && a.cost) { double t = 0.0; for (int q = 0; q < 16; ++q) t += s_cost[q]; *a.cost = t; }
+}
+
+// ------------------------------------------------------------------------------------------
+// The dense trainer SPLIT over 8 workgroups of one XCD (round 3; the float64 form the SNN-DAE script runs by default).
+// W [row][col] in float64 is 480 KB at 200 x 300: it fits no single CU's registers or LDS, and k_dae_dense_g above moves it
+// through one CU's port three and a half times per example (52 us per example).  Here workgroup c owns the hidden units
+// [c cw, (c + 1) cw), cw = ceil(col / 8) <= 64, and keeps ITS columns of W in registers for the whole pass (wave w: rows w, w + 16,
+// ...; lane: column) -- no global traffic for W at all.  Per example everything is local to the owner of a column (y = x W,
+// dy = d W, the update) except the reconstruction z_i = sigmoid(sum_j y_j W[i][j] + b'_i), a sum over ALL hidden units: every
+// workgroup publishes its partial row sums (row doubles, write-through stores), raises its flag, waits for the other seven and
+// adds the eight partials in workgroup order (the same order everywhere: all eight hold the same z, d, b').  One hand-off per
+// example (MI355X_MICROARCH.md "Valid forms": every handed-off byte stored and loaded sc1, stores drained before the flag, one
+// lane polls, the others load behind a barrier); the eight workgroups sit on one XCD (block ids 8 apart) so the exchange stays in
+// its L2.  Flags hold the example number + 1 and only grow; the exchange buffer has two parities (a workgroup rewrites parity p two
+// examples later, after it has seen every peer's next flag, which a peer raises only once it has read parity p).  A peer that
+// never arrives: bounded poll, error bit, every workgroup leaves.
+// ------------------------------------------------------------------------------------------
+constexpr int DSP_NS = 8;
+template <typename S> struct DenseSArgs {
+    S *W, *bhid, *bvis; const S* X; int64_t N; int row, col, cw; S lr; int skip_last; double* cost;
+    S* xch;                        // [2][DSP_NS][rowp] partial row sums
+    unsigned long long* flags;     // [DSP_NS] on 64-byte lines (stride 8)
+    int rowp; int* err;
+};
+
+template <typename S, int RPW>
+__global__ __launch_bounds__(1024) void k_dae_dense_split(const DenseSArgs<S> a)
+{
+    constexpr int RP = 16 * RPW;
+    __shared__ S s_x[RP], s_xn[RP], s_d[RP], s_bv[RP], s_zp[RP];
+    __shared__ S s_y[64], s_dy[64];
+    __shared__ S s_part[16][64];
+    __shared__ double s_cost[16];
+    __shared__ int s_bad;
+    if (blockIdx.x & 7) return;                                   // the eight working blocks are 8 apart: one XCD under round-robin placement
+    const int wg = blockIdx.x >> 3, tid = threadIdx.x, w = tid >> 6, l = tid & 63, row = a.row, col = a.col;
+    const int j = wg * a.cw + l;
+    const bool cact = l < a.cw && j < col;
+    S Wr[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) { const int i = w + 16 * r; Wr[r] = (cact && i < row) ? a.W[(size_t)i * col + j] : (S)0; }
+    S bh = (w == 0 && cact) ? a.bhid[j] : (S)0;
+    for (int i = tid; i < RP; i += 1024) { s_x[i] = i < row ? a.X[i] : (S)0; s_bv[i] = i < row ? a.bvis[i] : (S)0; s_xn[i] = (S)0; s_d[i] = (S)0; }
+    if (tid == 0) s_bad = 0;
+    double cost = 0.0;
+    __syncthreads();
+    {   // x W of the first example: a wave's share of the rows, then 16 partials per column
+        S p = (S)0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) p = fma(s_x[w + 16 * r], Wr[r], p);
+        s_part[w][l] = p;
+    }
+    __syncthreads();
+    for (int64_t n = 0; n < a.N; ++n) {
+        for (int i = tid; i < row; i += 1024) s_xn[i] = (n + 1 < a.N) ? a.X[(size_t)(n + 1) * row + i] : (S)0;
+        S y = (S)0;
+        if (w == 0) {
+            S t = bh;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += s_part[q][l];
+            y = cact ? sigm(t) : (S)0;
+            s_y[l] = y;
+        }
+        __syncthreads();
+        {   // this workgroup's share of z: row sums over ITS columns (wave reductions)
+            const S yl = s_y[l];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const S v = wave_sum(yl * Wr[r]);
+                if (l == 0) s_zp[w + 16 * r] = v;
+            }
+        }
+        __syncthreads();
+        {   // publish, signal, wait, gather
+            S* mine = a.xch + ((size_t)(n & 1) * DSP_NS + wg) * a.rowp;
+            for (int i = tid; i < row; i += 1024) __hip_atomic_store(mine + i, s_zp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.flags + wg * 8, (unsigned long long)(n + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < DSP_NS) {
+                int tries = 0;
+                while (__hip_atomic_load(a.flags + tid * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)(n + 1)) {
+                    if (++tries > (1 << 22)) { s_bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (s_bad) break;
+            const S* all = a.xch + (size_t)(n & 1) * DSP_NS * a.rowp;
+            for (int i = tid; i < row; i += 1024) {
+                S zs = s_bv[i];
+#pragma unroll
+                for (int c = 0; c < DSP_NS; ++c) zs += __hip_atomic_load(all + (size_t)c * a.rowp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 loads
+                const S zi = sigm(zs), xi = s_x[i];
+                s_d[i] = zi - xi;
+                if (wg == 0) cost += (double)xent(xi, zi);
+            }
+        }
+        __syncthreads();
+        {   // d W over the wave's rows
+            S p = (S)0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) p = fma(s_d[w + 16 * r], Wr[r], p);
+            s_part[w][l] = p;
+        }
+        __syncthreads();
+        const S lr = (a.skip_last && n + 1 == a.N) ? (S)0 : a.lr;
+        if (w == 0) {
+            S t = (S)0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += s_part[q][l];
+            const S dy = t * y * ((S)1 - y);
+            s_dy[l] = dy;
+            bh -= lr * dy;
+        }
+        __syncthreads();
+        {   // W <- W - lr (x (x) dy + d (x) y); the next example's x W rides on the same pass
+            const S dyl = s_dy[l], yl = s_y[l];
+            S p = (S)0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int i = w + 16 * r;
+                const S wv = Wr[r] - lr * fma(s_x[i], dyl, s_d[i] * yl);
+                Wr[r] = cact ? wv : (S)0;
+                p = fma(s_xn[i], Wr[r], p);
+            }
+            __syncthreads();                                       // every wave has read s_part / s_x of this example
+            s_part[w][l] = p;
+        }
+        for (int i = tid; i < row; i += 1024) { s_bv[i] -= lr * s_d[i]; s_x[i] = s_xn[i]; }
+        __syncthreads();
+    }
+    if (s_bad) { if (tid == 0) atomicOr(a.err, 4); return; }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) { const int i = w + 16 * r; if (cact && i < row) a.W[(size_t)i * col + j] = Wr[r]; }
+    if (w == 0 && cact) a.bhid[j] = bh;
+    if (wg == 0) {
+        for (int i = tid; i < row; i += 1024) a.bvis[i] = s_bv[i];
+        const double cwv = wave_sum(cost);                       // every thread i < row carried its row's terms
+        if (l == 0) s_cost[w] = cwv;
+        __syncthreads();
+        if (tid == 0 && a.cost) { double t = 0.0; for (int q = 0; q < 16; ++q) t += s_cost[q]; *a.cost = t; }
+    }
 }
 
 struct DenseArgs { float *W, *bhid, *bvis; const float* X; int64_t N; int row, col; float lr; int skip_last; double* cost; };
@@ -421,6 +565,31 @@ int dense_g_epoch_t(S* W, S* bhid, S* bvis, const S* X, int64_t N, int row, int 
     DevDouble dc;
     DHK(hipMalloc((void**)&dc.p, 8));
     double* dcost = dc.p;
+    {   // float64, shapes the split form holds (col <= 512, row <= 512): eight workgroups with W in registers ($DAE_SPLIT=0: the one-workgroup form below)
+        const char* ev = getenv("DAE_SPLIT");
+        if (sizeof(S) == 8 && col <= 64 * DSP_NS && row <= 16 * 32 && !(ev && ev[0] == '0')) {
+            const int rowp = (row + 15) / 16 * 16, cw = (col + DSP_NS - 1) / DSP_NS;
+            struct Scratch { char* p = nullptr; ~Scratch() { if (p) hipFree(p); } } sc;
+            const size_t xb = (size_t)2 * DSP_NS * rowp * sizeof(S), fb = (size_t)DSP_NS * 64, total = xb + fb + 64;
+            DHK(hipMalloc((void**)&sc.p, total));
+            DHK(hipMemsetAsync(sc.p, 0, total, st));
+            DenseSArgs<S> sa{W, bhid, bvis, X, N, row, col, cw, lr, skip_last, dcost, reinterpret_cast<S*>(sc.p),
+                             reinterpret_cast<unsigned long long*>(sc.p + xb), rowp, reinterpret_cast<int*>(sc.p + xb + fb)};
+            const int rpw = (row + 15) / 16;
+            if (rpw <= 8) hipLaunchKernelGGL((k_dae_dense_split<S, 8>), dim3(8 * DSP_NS), dim3(1024), 0, st, sa);
+            else if (rpw <= 13) hipLaunchKernelGGL((k_dae_dense_split<S, 13>), dim3(8 * DSP_NS), dim3(1024), 0, st, sa);
+            else if (rpw <= 19) hipLaunchKernelGGL((k_dae_dense_split<S, 19>), dim3(8 * DSP_NS), dim3(1024), 0, st, sa);
+            else hipLaunchKernelGGL((k_dae_dense_split<S, 32>), dim3(8 * DSP_NS), dim3(1024), 0, st, sa);
+            DHK(hipGetLastError());
+            double c = 0.0; int bad = 0;
+            DHK(hipMemcpyAsync(&c, dcost, 8, hipMemcpyDeviceToHost, st));
+            DHK(hipMemcpyAsync(&bad, sa.err, 4, hipMemcpyDeviceToHost, st));
+            DHK(hipStreamSynchronize(st));
+            if (bad) DFAIL(FNN_ERR_HIP, "dae_dense_epoch_f64: a workgroup of the split trainer gave up waiting for its peers (DAE_SPLIT=0 selects the one-workgroup form); the parameters of this pass are invalid");
+            if (cost_sum_out) *cost_sum_out = c;
+            return FNN_OK;
+        }
+    }
     const int CP = (col + 63) / 64 * 64;
     const size_t lds = (size_t)(1024 + 2 * CP + 4 * row + 2) * sizeof(S) + 16 * 8;
     DenseGArgs<S> a{W, bhid, bvis, X, N, row, col, lr, skip_last, dcost};

@@ -203,13 +203,14 @@ __global__ __launch_bounds__(256) void k_rbm_sparse32(const SparseArgs a)
 // k_rbm_batch: one workgroup per example slot (thread = hidden unit), examples e = blockIdx, + gridDim, ...;
 // row deltas are ACCUMULATED into dW / dvis (zero outside this function) with float atomics, so that no example
 // reads a row another one has already moved; k_rbm_apply then moves every touched row once (grab-and-zero);
-// k_rbm_batch_tail reduces the per-workgroup partials of wstep / hidbias / error in a fixed order.  The row sums
+// k_rbm_batch_tail / k_rbm_tail_apply reduce the per-workgroup partials of wstep / hidbias / error in a fixed order.  The row sums
 // depend on the order the atomics land in (rounding only): this mode is not bit-reproducible, the online one is.
 // ------------------------------------------------------------------------------------------
 struct BatchArgs {
     const float *W, *visbias, *hidbias, *wstep; float *dW, *dvis; const int32_t* vid; const uint8_t* vval; const float* unif;
     int M, H, S; float wcost, r_vis, r_w, mom; float* part_w; float* part_h; double* part_e;
     float* hbuf; float* visbuf;       // SORTED form: hid / hid2 of every example [M][2][H] and its reconstructions [M][S] (the row update recomputes the deltas)
+    int* owner_cnt;                   // SORTED form: the row update's counter of multi-chunk runs, zeroed here
 };
 
 template <bool SORTED>
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void k_rbm_batch(const BatchArgs a)
     __shared__ int s_id[32];
     const int tid = threadIdx.x, H = a.H, S = a.S;
     const bool act = tid < H;
+    if (SORTED && blockIdx.x == 0 && tid == 0) *a.owner_cnt = 0;
     const float hb = act ? a.hidbias[tid] : 0.f;
     float ws0[32], wsum[32], hacc = 0.f;
 #pragma unroll
@@ -429,12 +431,15 @@ __global__ __launch_bounds__(256) void k_rbm_keys(const int32_t* __restrict__ vi
     keys[gid] = (row << GROUP_INDEX_BITS) | (unsigned long long)(gid % seg_n);
 }
 
-// 64 elements x 16 groups of workgroup partials per block: a thread sums every 16th partial of its element (eight loads
-// in flight at a time), the 16 group sums meet in LDS in a fixed order (deterministic).
-// sums_out != null (data parallelism): the sums leave unapplied, the caller all-reduces them and k_rbm_tail_apply does the rest
-__global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ part_w,
-                                                         const float* __restrict__ part_h, const double* __restrict__ part_e, int nwg, int M,
-                                                         int H, int S, float mom, float r_hid, double* __restrict__ err_acc, float* __restrict__ sums_out)
+// The per-workgroup partials of wstep / hidbias (up to 1,024 x 6,600 floats = 27 MB at M = 4096) in two levels, fixed order
+// (deterministic).  Level 1: block (bx, by) owns 64 elements and the partials w = by (mod TAIL_NG): a thread sums every
+// (16 TAIL_NG)-th partial of its element with all its loads in flight, the 16 group sums meet in LDS -> part2[by][element].
+// 104 x 8 blocks instead of round 2's 104 (which ran at 0.4 TB/s: 66 us, the longest kernel of the mini-batch after the atomics
+// were gone).  Level 2 (k_rbm_tail_apply): the TAIL_NG sums of an element, then the update -- or, under data parallelism, the
+// all-reduce first.
+constexpr int TAIL_NG = 8;
+__global__ __launch_bounds__(1024) void k_rbm_batch_tail(const float* __restrict__ part_w, const float* __restrict__ part_h, const double* __restrict__ part_e,
+                                                         int nwg, int H, int S, double* __restrict__ err_acc, float* __restrict__ part2)
 {
     __shared__ float s_p[16][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -443,10 +448,10 @@ __global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wst
     if (i < n) {
         const float* base = i < nW ? part_w + i : part_h + (i - nW);
         const size_t stride = i < nW ? (size_t)nW : (size_t)H;
-        for (int w0 = grp; w0 < nwg; w0 += 16 * 8) {
+        for (int w0 = blockIdx.y * 16 + grp; w0 < nwg; w0 += 16 * TAIL_NG * 8) {
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int w = w0 + 16 * k; v[k] = w < nwg ? base[(size_t)w * stride] : 0.f; }
+            for (int k = 0; k < 8; ++k) { const int w = w0 + 16 * TAIL_NG * k; v[k] = w < nwg ? base[(size_t)w * stride] : 0.f; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[k];
         }
@@ -457,24 +462,28 @@ __global__ __launch_bounds__(1024) void k_rbm_batch_tail(float* __restrict__ wst
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += s_p[g][el];
-        if (sums_out) sums_out[i] = t;
-        else if (i < nW) wstep[i] = mom * wstep[i] + t / (float)M;
-        else hidbias[i - nW] += r_hid * t;
+        part2[(size_t)blockIdx.y * n + i] = t;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         double e = 0.0;
         for (int w = 0; w < nwg; ++w) e += part_e[w];
         *err_acc += e;
     }
 }
 
-__global__ void k_rbm_tail_apply(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ sums, int nW, int H, int M,
-                                 float mom, float r_hid)
+// sums != null: the TAIL_NG level-1 sums of every element -> sums (what data parallelism all-reduces); apply = 1: wstep / hidbias from
+// `src` (part2 with ng = TAIL_NG, or the all-reduced sums with ng = 1)
+__global__ void k_rbm_tail_apply(float* __restrict__ wstep, float* __restrict__ hidbias, const float* __restrict__ src, int ng, int nW, int H, int M,
+                                 float mom, float r_hid, float* __restrict__ sums, int apply)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nW + H) return;
-    if (i < nW) wstep[i] = mom * wstep[i] + sums[i] / (float)M;
-    else hidbias[i - nW] += r_hid * sums[i];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = nW + H;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int g = 0; g < ng; ++g) t += src[(size_t)g * n + i];
+    if (sums) sums[i] = t;
+    if (!apply) return;
+    if (i < nW) wstep[i] = mom * wstep[i] + t / (float)M;
+    else hidbias[i - nW] += r_hid * t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -714,12 +723,32 @@ static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, f
     const char* ev = getenv("RBM_BATCH_ATOMICS");
     const bool sorted = H % 4 == 0 && (int64_t)M * S <= ((int64_t)1 << GROUP_INDEX_BITS) && !(ev && ev[0] == '1');
     float *part_w = nullptr, *part_h = nullptr; double *part_e = nullptr, *d_err = nullptr;
-    std::vector<void*> owned;
-    auto cleanup = [&]() { for (void* q : owned) if (q) hipFree(q); };
-#define RAL(ptr, bytes) do { void* q_ = nullptr; hipError_t e_ = hipMalloc(&q_, (bytes)); if (e_ != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e_); cleanup(); return FNN_ERR_NOMEM; } owned.push_back(q_); ptr = static_cast<decltype(ptr)>(q_); } while (0)
+    // scratch: ONE arena per host thread, grown on demand and kept between calls (a dozen hipMalloc / hipFree pairs per call cost
+    // more than a mini-batch: 0.29 -> 0.2x ms per mini-batch of 4096 in the bench, which calls once per 16 mini-batches)
+    struct Arena { char* base = nullptr; size_t cap = 0, used = 0; int dev = -1; ~Arena() { /* freed with the process */ } };
+    static thread_local Arena arena;
+    int cur_dev = 0; hipGetDevice(&cur_dev);
+    size_t need_total = 0;
+    auto rup256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    {   // everything this call will carve out of the arena (the same expressions as the RAL lines below)
+        const int seg_n0 = M * S, nchunk0 = (seg_n0 + RCH - 1) / RCH, G0 = 16;
+        need_total = rup256((size_t)nwg_max * S * H * 4) + rup256((size_t)nwg_max * H * 4) + rup256((size_t)nwg_max * 8) + rup256(8) + rup256((size_t)(S * H + H) * 4) + rup256((size_t)8 * (S * H + H) * 4);
+        if (sorted) need_total += rup256((size_t)M * 2 * H * 4) + rup256((size_t)seg_n0 * 4) + rup256((size_t)nchunk0 * 2 * (H + 4) * 8) + rup256((size_t)nchunk0 * sizeof(int4)) +
+                                  rup256(4) + 2 * rup256((size_t)G0 * seg_n0 * 8) + rup256((size_t)G0 * seg_n0 * sizeof(int4)) + rup256(radix_sort_hist_bytes(G0, seg_n0));
+    }
+    if (arena.dev != cur_dev || arena.cap < need_total) {
+        if (arena.base) { hipDeviceSynchronize(); hipFree(arena.base); arena.base = nullptr; arena.cap = 0; }
+        void* q = nullptr;
+        if (hipMalloc(&q, need_total) != hipSuccess) { (void)hipGetLastError(); RFAIL(FNN_ERR_NOMEM, "rbm_sparse_batch: hipMalloc of the scratch arena failed"); }
+        arena.base = static_cast<char*>(q); arena.cap = need_total; arena.dev = cur_dev;
+    }
+    arena.used = 0;
+    auto cleanup = [&]() {};
+#define RAL(ptr, bytes) do { ptr = reinterpret_cast<decltype(ptr)>(arena.base + arena.used); arena.used += rup256((size_t)(bytes)); } while (0)
     RAL(part_w, (size_t)nwg_max * S * H * 4); RAL(part_h, (size_t)nwg_max * H * 4); RAL(part_e, (size_t)nwg_max * 8); RAL(d_err, 8);
-    float* sums = nullptr;
+    float *sums = nullptr, *part2 = nullptr;
     if (allreduce) RAL(sums, (size_t)(S * H + H) * 4);
+    RAL(part2, (size_t)TAIL_NG * (S * H + H) * 4);
     RCK(hipMemsetAsync(d_err, 0, 8, st));
     const int seg_n = M * S, nchunk = (seg_n + RCH - 1) / RCH, GROUP = 16;
     float *hbuf = nullptr, *visbuf = nullptr; double* spart = nullptr; int4 *owners = nullptr, *rec = nullptr; int* owner_cnt = nullptr;
@@ -746,10 +775,10 @@ static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, f
             rec_mb = rec + (size_t)(mb % GROUP) * seg_n;
         }
         BatchArgs a{W, visbias, hidbias, wstep, dW, dvis, vid + n0 * S, vval + n0 * S, unif + n0 * H, m, H, S, weightcost, rate_vis, rate_w,
-                    momentum, part_w, part_h, part_e, hbuf, visbuf};
+                    momentum, part_w, part_h, part_e, hbuf, visbuf, nullptr};
         if (sorted) {
+            a.owner_cnt = owner_cnt;                               // zeroed by workgroup 0 of the compute launch (a fill launch costs 4.6 us)
             hipLaunchKernelGGL(k_rbm_batch<true>, dim3(nwg), dim3(256), 0, st, a);
-            RCK(hipMemsetAsync(owner_cnt, 0, 4, st));
             RbmScatArgs sa{rec_mb, seg_n, hbuf, visbuf, vval + n0 * S, wstep, W, visbias, H, S, weightcost, rate_vis, rate_w, momentum,
                            spart, owners, owner_cnt};
             const long nthr = (long)nchunk * (H / 4);
@@ -759,15 +788,18 @@ static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, f
             hipLaunchKernelGGL(k_rbm_batch<false>, dim3(nwg), dim3(256), 0, st, a);
             hipLaunchKernelGGL(k_rbm_apply, dim3((unsigned)(m * S)), dim3(64), 0, st, W, dW, visbias, dvis, vid + n0 * S, m, H, S);
         }
-        hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((S * H + H + 63) / 64)), dim3(1024), 0, st, wstep, hidbias, part_w, part_h,
-                           part_e, nwg, m, H, S, momentum, rate_hid, d_err, sums);
+        const int nel = S * H + H;
+        hipLaunchKernelGGL(k_rbm_batch_tail, dim3((unsigned)((nel + 63) / 64), TAIL_NG), dim3(1024), 0, st, part_w, part_h, part_e, nwg, H, S, d_err, part2);
+        // level 2: the TAIL_NG sums of every element, then the update (single process) or the sums for the all-reduce
+        hipLaunchKernelGGL(k_rbm_tail_apply, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, wstep, hidbias, part2, TAIL_NG, S * H, H, m, momentum,
+                           rate_hid, sums, allreduce ? 0 : 1);
         if (allreduce) {
             // every rank runs the same number of mini-batches (its shard of each): the global count is what the mean divides by.
             // A short LAST mini-batch: the caller passes shards of the same global tail, so the ratio m / M carries over
             if (allreduce(ctx, sums, (int64_t)(S * H + H), (void*)st) != 0) { cleanup(); RFAIL(FNN_ERR_HIP, "rbm_sparse_batch_dp: the all-reduce callback failed"); }
             const int mg = (int)((int64_t)M_global * m / M);
-            hipLaunchKernelGGL(k_rbm_tail_apply, dim3((unsigned)((S * H + H + 255) / 256)), dim3(256), 0, st, wstep, hidbias, sums, S * H, H, mg > 0 ? mg : 1,
-                               momentum, rate_hid);
+            hipLaunchKernelGGL(k_rbm_tail_apply, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, wstep, hidbias, sums, 1, S * H, H, mg > 0 ? mg : 1,
+                               momentum, rate_hid, (float*)nullptr, 1);
         }
     }
     hipError_t le = hipGetLastError();
