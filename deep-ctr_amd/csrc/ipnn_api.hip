@@ -1078,11 +1078,6 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL((k_sortA<unsigned>), dim3(4 * F), dim3(256), 0, ss, so);
             hipLaunchKernelGGL((k_sortB<unsigned>), dim3(16 * F), dim3(256), SORT_N * 4, ss, so);
         }
-        if (h->pf_pending) {      // the NEXT step's masks: transposed now, on the side stream (idle under the strips), into the other set;
-            h->pf_pending = false;   // the join at the end of this step orders it before the next one
-            mask_T(h->pf_masks, h->pf_B, h->maskT_alt, ss);
-            h->pf_ready = true;
-        }
     }
     {
         IpProf ps(h, "ip_fwd");
@@ -1272,6 +1267,22 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             const size_t n = (size_t)h->n_rows * SLOT;
             hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ss, h->table16, h->tm, h->tv, h->tG, n,
                                lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
+        }
+        if (h->pf_pending) {
+            // the NEXT step's keep-masks: transposed at the END of the side chain (beside the weight gradients and the dense update) into
+            // the other set; the join at the end of this step orders it before the next one.  (Beside the strip kernels -- the side
+            // stream is idle there -- it cost more than it saved: 0.265 -> 0.270 ms per step, the strips are bound by the CUs' ports.)
+            h->pf_pending = false;
+            const int Bam = rup(h->pf_B, 256);
+            MaskTArgs ma{};
+            int tiles = 0;
+            for (int t = 0; t <= L; ++t) {
+                ma.src[t] = h->pf_masks[t]; ma.dst[t] = h->maskT_alt[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
+                tiles += (Bam / 64) * (h->Dp[t] / 64);
+            }
+            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = h->pf_B; ma.Ba = Bam; ma.ldT = ldT;
+            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, ss, ma);
+            h->pf_ready = true;
         }
         if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
     }

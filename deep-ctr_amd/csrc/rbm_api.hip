@@ -464,10 +464,17 @@ __global__ __launch_bounds__(1024) void k_rbm_batch_tail(const float* __restrict
         for (int g = 0; g < 16; ++g) t += s_p[g][el];
         part2[(size_t)blockIdx.y * n + i] = t;
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        // the workgroups' error sums: a fixed-shape tree over the block (one thread walking the 1,024 partials paid a memory round
+        // trip per partial -- 63 us, the whole length of this launch, as profiles/r03_rbm_kernel_stats.csv showed)
+        __shared__ double s_e[1024];
+        __syncthreads();
         double e = 0.0;
-        for (int w = 0; w < nwg; ++w) e += part_e[w];
-        *err_acc += e;
+        for (int w = threadIdx.x; w < nwg; w += 1024) e += part_e[w];
+        s_e[threadIdx.x] = e;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_e[threadIdx.x] += s_e[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) *err_acc += s_e[0];
     }
 }
 
@@ -717,7 +724,9 @@ static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, f
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) RFAIL(FNN_ERR_HIP, "no HIP device (no CPU fallback)");
     hipStream_t st = (hipStream_t)stream;
-    const int nwg_max = (int)std::min<int64_t>(M, 1024);       // 4 workgroups per CU; more examples than that: several per workgroup
+    int nwg_cap = 1024;                                        // 4 workgroups per CU; more examples than that: several per workgroup
+    if (const char* e = getenv("RBM_BATCH_WGS")) nwg_cap = std::max(64, std::min(4096, atoi(e)));     // tuning knob
+    const int nwg_max = (int)std::min<int64_t>(M, nwg_cap);
     // the row update without atomics needs 16-byte quarter-columns (H % 4 == 0) and entry indices that fit the key (M * S <= 2^20);
     // anything else keeps the atomic form ($RBM_BATCH_ATOMICS=1 forces it: A/B measurements)
     const char* ev = getenv("RBM_BATCH_ATOMICS");
