@@ -933,8 +933,6 @@ def bench_ipnn(args):
 
     def step(i):
         b = i % NB
-        if not os.environ.get('IPNN_BENCH_NOPREFETCH'):
-            lib.ipnn_prefetch_masks(h, marr[(i + 1) % NM], B)       # the NEXT step's keep-masks: transposed beside this step (a hint, like fnn_prefetch_ids)
         rc = lib.ipnn_train_step(h, ids.data_ptr() + b * B * F * 4, y.data_ptr() + b * B * 4, B, marr[i % NM], None, None)
         if rc != 0:
             raise RuntimeError(lib.ipnn_last_error(h).decode())

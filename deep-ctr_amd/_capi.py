@@ -120,7 +120,6 @@ IPNN_SIGNATURES = {
     "ipnn_set_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_get_layer": (_i, [_vp, _i, _vp, _vp]),
     "ipnn_train_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.POINTER(_f)]),
-    "ipnn_prefetch_masks": (_i, [_vp, _vp, _i]),
     "ipnn_set_loss_mean": (_i, [_vp, _i]),
     "ipnn_predict": (_i, [_vp, _vp, _i, _vp]),
     "ipnn_eval": (_i, [_vp, _vp, _vp, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

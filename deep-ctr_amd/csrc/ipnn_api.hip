@@ -999,8 +999,6 @@ struct ipnn_handle {
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
-    // ipnn_prefetch_masks: the NEXT step's keep-masks, transposed on the side stream during the current step into the other set
-    std::vector<uint8_t*> maskT_alt; const uint8_t* pf_masks[IPNN_MAX_HIDDEN + 1] = {}; int pf_B = 0; bool pf_pending = false, pf_ready = false;
     int tail_split = 1;                              // IPNN_TAIL_SPLIT=0: the whole stack in one strip launch per direction (round 2's form)
     bool duo_failed = false;                         // a pair gave up once: every later train step is refused until the handle is re-created
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
@@ -1046,28 +1044,20 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         // the transposed keep-masks (needed from the first product on) go first on the main stream
         hipStream_t ss = h->st2 ? h->st2 : h->st;
         if (h->st2) { IHK(h, hipEventRecord(h->ev_fork, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_fork, 0)); }
-        auto mask_T = [&](const uint8_t* const* src, int Bm, std::vector<uint8_t*>& dst, hipStream_t on) {
-            const int Bam = rup(Bm, 256);
+        if (drop) {   // keep-masks of all layers -> transposed, tiled, zero padded, slot-ordered for layer 0
             MaskTArgs ma{};
             int tiles = 0;
             for (int t = 0; t <= L; ++t) {
-                ma.src[t] = src[t]; ma.dst[t] = dst[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
-                tiles += (Bam / 64) * (h->Dp[t] / 64);
+                ma.src[t] = masks[t]; ma.dst[t] = h->maskT[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
+                tiles += (Ba / 64) * (h->Dp[t] / 64);
             }
-            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = Bm; ma.Ba = Bam; ma.ldT = ldT;
-            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, on, ma);
-        };
-        bool hit = false;
-        if (drop && h->pf_ready && h->pf_B == B) {      // announced before the previous step (ipnn_prefetch_masks): already transposed, beside that step
-            hit = true;
-            for (int t = 0; t <= L; ++t) hit = hit && masks[t] == h->pf_masks[t];
-            if (hit) std::swap(h->maskT, h->maskT_alt);
-        }
-        h->pf_ready = false;
-        if (drop && !hit) {   // keep-masks of all layers -> transposed, tiled, zero padded, slot-ordered for layer 0
+            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
             // on the MAIN stream by default: a cross-stream event on the way into the first strip kernel costs more (10-20 us of
-            // wait resolution, measured on the kernel trace) than the 10 us the transposition takes in line
-            mask_T(masks, B, h->maskT, h->mask_side ? ss : h->st);
+            // wait resolution, measured on the kernel trace) than the 10 us the transposition takes in line.  (Round 3 also tried
+            // transposing the NEXT step's masks ahead, on the side stream -- beside the strips: 0.265 -> 0.270 ms per step, at the end
+            // of the side chain beside the weight gradients: 0.286 -> 0.302 on a slower box: every kernel of this step is bound by
+            // the CUs' ports or the L2, and a co-running launch takes what it saves.  Not kept.)
+            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->mask_side ? ss : h->st, ma);
             if (h->st2 && h->mask_side) IHK(h, hipEventRecord(h->ev_mask, h->st2));
         }
         SortArgs so{ids, B, F, h->n_rows, h->rec, h->owner_cnt, F, h->skeys};
@@ -1268,22 +1258,6 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ss, h->table16, h->tm, h->tv, h->tG, n,
                                lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
         }
-        if (h->pf_pending) {
-            // the NEXT step's keep-masks: transposed at the END of the side chain (beside the weight gradients and the dense update) into
-            // the other set; the join at the end of this step orders it before the next one.  (Beside the strip kernels -- the side
-            // stream is idle there -- it cost more than it saved: 0.265 -> 0.270 ms per step, the strips are bound by the CUs' ports.)
-            h->pf_pending = false;
-            const int Bam = rup(h->pf_B, 256);
-            MaskTArgs ma{};
-            int tiles = 0;
-            for (int t = 0; t <= L; ++t) {
-                ma.src[t] = h->pf_masks[t]; ma.dst[t] = h->maskT_alt[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
-                tiles += (Bam / 64) * (h->Dp[t] / 64);
-            }
-            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = h->pf_B; ma.Ba = Bam; ma.ldT = ldT;
-            hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, ss, ma);
-            h->pf_ready = true;
-        }
         if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
     }
     {   // all weight gradients: gW_t [Dp_{t-1}][Dp_t] = a_{t-1}^T . delta l_t, contraction over the examples,
@@ -1423,8 +1397,6 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     }
     h->maskT.assign(h->L + 1, nullptr);
     for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT[t], Ba * h->Dp[t]));
-    h->maskT_alt.assign(h->L + 1, nullptr);
-    for (int t = 0; t <= h->L; ++t) IK(al((void**)&h->maskT_alt[t], Ba * h->Dp[t]));
     h->slab_stride = nw;
     IK(al((void**)&h->slab, (size_t)h->splitk * nw * 4));
     IK(al((void**)&h->emb, Ba * h->F * SLOT * 4));
@@ -1460,7 +1432,6 @@ int ipnn_destroy(ipnn_handle* h)
     for (auto v : {&h->wf, &h->wb, &h->a, &h->aT, &h->dl, &h->dlT}) for (void* p : *v) if (p) hipFree(p);
     for (float* p : h->W) if (p) hipFree(p);
     for (uint8_t* p : h->maskT) if (p) hipFree(p);
-    for (uint8_t* p : h->maskT_alt) if (p) hipFree(p);
     for (float* p : h->Wm) if (p) hipFree(p);
     for (float* p : h->Wv) if (p) hipFree(p);
     for (float* p : {h->tm, h->tv, h->tG, h->bmv}) if (p) hipFree(p);
@@ -1609,15 +1580,6 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B, c
         IHK(h, hipMemcpyAsync(loss_sum_out, h->loss_dev, 4, hipMemcpyDeviceToHost, h->st));
         return ipnn_sync(h);
     }
-    return FNN_OK;
-}
-
-int ipnn_prefetch_masks(ipnn_handle* h, const uint8_t* const* masks_next, int B_next)
-{
-    if (!h || !masks_next) return FNN_ERR_ARG;
-    if (B_next < 1 || B_next > h->Bmax) IFAIL(h, FNN_ERR_ARG, "B must be in [1, max_batch]");
-    for (int t = 0; t <= h->L; ++t) { if (!masks_next[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry"); h->pf_masks[t] = masks_next[t]; }
-    h->pf_B = B_next; h->pf_pending = true;      // transposed by the next ipnn_train_step, beside its stack
     return FNN_OK;
 }
 

@@ -103,15 +103,6 @@ class IPNNEngine(object):
         scale = 1.0 if self.reduce == 'sum' else 1.0 / B     # the library returns the sum of the per-example losses
         return {'loss': float(loss.value) * scale if want_loss else None, 'logits': logits}
 
-    def prefetch_masks(self, masks):
-        """ipnn_prefetch_masks: announce the DEVICE uint8 tensors that the train step AFTER the next call will be given as `masks`
-        (the very same tensors): their transposition then rides beside the coming step.  A scheduling hint; results identical."""
-        torch = self._torch
-        assert all(isinstance(m, torch.Tensor) and m.is_cuda and m.dtype == torch.uint8 and m.is_contiguous() for m in masks)
-        marr = (C.c_void_p * len(masks))(*[m.data_ptr() for m in masks])
-        self._ck(self.lib.ipnn_prefetch_masks(self.h, marr, masks[0].shape[0]))
-        self._keep_pf = list(masks)
-
     def predict(self, ids):
         torch = self._torch
         ids_t = self._dev(ids, torch.int32)

@@ -81,12 +81,6 @@ int ipnn_get_layer(ipnn_handle* h, int layer, float* W, float* bias);
  * One SGD step.  logits_out [B] (device, nullable); loss_sum_out (host, nullable: synchronises). */
 int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B,
                     const uint8_t* const* masks, float* logits_out, float* loss_sum_out);
-/* Optional: hand the keep-masks of an UPCOMING ipnn_train_step to the library before the CURRENT one is called (DEVICE pointers; the
- * same pointers and B as the later call, contents unchanged until then).  The epilogues read the masks transposed and tiled
- * (a lane's four rows in one dword); that transposition of the NEXT step's masks then rides on the side stream beside the
- * current step's stack instead of heading the next step's critical path.  Purely a scheduling hint (like fnn_prefetch_ids):
- * results are identical with or without it, and a step whose masks were not announced transposes them in line. */
-int ipnn_prefetch_masks(ipnn_handle* h, const uint8_t* const* masks_next, int B_next);
 /* Loss reduction of the following train steps: 0 (default) = tf.reduce_sum, 1 = tf.reduce_mean over the batch
  * (`_ptmzr_argv[-1]`, python/FNN_IP_L7.py:83-86): every gradient of a step is scaled by 1 / B.  loss_sum_out stays the
  * SUM of the per-example cross-entropies (divide by B on the host for the mean). */

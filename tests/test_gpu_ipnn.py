@@ -373,32 +373,3 @@ def test_strip_pairs_are_bit_identical_to_single_strips(built, monkeypatch):
     for t in range(len(Wa)):
         assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t
 
-
-def test_prefetched_masks_change_nothing(built):
-    """ipnn_prefetch_masks: the next step's keep-masks transposed on the side stream during the current step.  Four bf16 steps of
-    the L7 stack with every step's masks announced one step ahead (and one announcement that is NOT honoured: other masks
-    arrive) against the same steps without the hint: logits and every parameter bit for bit."""
-    import torch
-    hidden = [1000, 800, 600, 400, 200, 100, 50]
-    B, steps = 1024, 4
-    table, ids, y, params, _, d = problem(B * steps, hidden, seed=31, n_rows=2000, scale=0.05)
-    dev = torch.device('cuda', 0)
-    masks = [[(torch.rand((B, d[t]), device=dev, generator=torch.Generator(device=dev).manual_seed(100 * s + t)) < 0.5).to(torch.uint8).contiguous()
-              for t in range(len(hidden) + 1)] for s in range(steps)]
-    decoy = [m.clone() for m in masks[0]]
-    res = []
-    for hint in (True, False):
-        eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='bf16', lr=0.01, keep_prob=0.5)
-        eng.set_params(table, params['b'], params['W'], params['bias'])
-        logits = []
-        for s in range(steps):
-            sl = slice(s * B, (s + 1) * B)
-            if hint:
-                eng.prefetch_masks(masks[s + 1] if s + 1 < steps and s != 1 else decoy)      # before step 2: a wrong announcement
-            logits.append(eng.train_step(ids[sl], y[sl], masks[s], want_logits=True)['logits'].cpu().numpy().copy())
-        res.append((np.concatenate(logits), eng.get_params()))
-        eng.close()
-    (la, (ba, Wa, bsa)), (lb, (bb, Wb, bsb)) = res
-    assert np.array_equal(la, lb) and ba == bb
-    for t in range(len(Wa)):
-        assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t

@@ -17,3 +17,7 @@ step ip_nopf2 300 env IPNN_BENCH_NOPREFETCH=1 python bench.py $B
 for f in ip_pf ip_nopf ip_pf2 ip_nopf2; do grep -o '"ms_per_step": [0-9.]*' gpurun_out/$f.log | head -1; done
 step rbm_sorted 400 python bench.py --workload rbm --no-cpu-baseline
 grep -o '"sparse_minibatch_4096": {[^}]*}' gpurun_out/rbm_sorted.log | cut -c1-220
+step rbm_wgs2048 400 env RBM_BATCH_WGS=2048 python bench.py --workload rbm --no-cpu-baseline
+grep -o '"sparse_minibatch_4096": {[^}]*}' gpurun_out/rbm_wgs2048.log | cut -c1-120
+step rbm_wgs512 400 env RBM_BATCH_WGS=512 python bench.py --workload rbm --no-cpu-baseline
+grep -o '"sparse_minibatch_4096": {[^}]*}' gpurun_out/rbm_wgs512.log | cut -c1-120
