@@ -483,6 +483,7 @@ def bench_fnn(args, precision, snn):
             ev = kern_ms.get('empty') or 0.0
             out['data_parallel'] = {'collective': collective, 'sparse_rows': args.dp_sparse if not snn else 'local',
                                     'payload': cfg['payload'], 'exchange_region': cfg['region'],
+                                    'p2p_max_flag_wait_us': eng.dp_p2p_max_wait_us() if p2p else None,     # longest wait for a peer's flag in any step (rank skew)
                                     # event-bracketed slot of the collective on rank 0, the event pair's own cost taken off; for p2p the
                                     # slot is the update launch that performs the all-reduce (wait for the peers + sum + update)
                                     'collective_us': max(0.0, ((kern_ms.get('p2p_update') if p2p else kern_ms.get('allreduce')) or 0.0) - ev) * 1e3,

@@ -67,6 +67,7 @@ SIGNATURES = {
     "fnn_dp_p2p_attach": (_i, [_vp, _vp, _i]),
     "fnn_dp_set_collective": (_i, [_vp, _i]),
     "fnn_dp_get_config": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "fnn_dp_p2p_max_wait_us": (_i, [_vp, C.POINTER(C.c_double)]),
     "fnn_step_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "fnn_dense_grad_bucket": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "fnn_step_scatter": (_i, [_vp]),

@@ -103,6 +103,8 @@ struct fnn_handle {
     float* xr = nullptr; size_t xr_nbp = 0, xr_bytes = 0; int xr_kind = 0; bool xr_same_process = false;
     float* peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool peer_opened[8] = {false, false, false, false, false, false, false, false};
     bool p2p_attached = false; unsigned long long dp_step_no = 0;
+    unsigned long long p2p_timeout_ticks = 3000000000ull;      // 30 s of the 100 MHz clock ($FNN_P2P_TIMEOUT_MS)
+    unsigned long long* p2p_wait_max = nullptr;                // device word: the longest flag wait so far (diagnostic)
     int step_bsize = 0;                 // its b_size (the decay table is rebuilt with it when a global batch outgrows the table)
     // profiling
     bool prof = false;
@@ -364,6 +366,7 @@ template <typename T> int dp_finish_bucket(fnn_handle* h, bool in_region)
         for (int r = 0; r < 8; ++r) pa.peer[r] = h->peer[r];
         pa.world = h->dp_world; pa.rank = h->dp_rank; pa.step = h->dp_step_no + 1;
         pa.bucket_off = (size_t)(h->dp_step_no & 1) * h->xr_nbp; pa.flag_off = 2 * h->xr_nbp * sizeof(float); pa.err = h->err_flag;
+        pa.timeout_ticks = h->p2p_timeout_ticks; pa.wait_max = h->p2p_wait_max;
         const unsigned nblk = (unsigned)((h->nw12 / 4 + 255) / 256 + (h->nw - h->nw12 + h->nbag + 255) / 256);
         hipLaunchKernelGGL((k_p2p_update<T>), dim3(nblk), dim3(256), 0, h->st, pa, h->master, h->cfg.lr,
                            h->cfg.lambda1, h->cfg.reg_all, h->K1p, h->H1p, h->H2p, (T*)h->w1, (T*)h->w1t, (T*)h->w2, (T*)h->w2t,
@@ -693,6 +696,7 @@ void p2p_release(fnn_handle* h)
         h->peer[r] = nullptr; h->peer_opened[r] = false;
     }
     if (h->xr) hipFree(h->xr);
+    if (h->p2p_wait_max) { hipFree(h->p2p_wait_max); h->p2p_wait_max = nullptr; }
     h->xr = nullptr; h->xr_kind = 0; h->p2p_attached = false; h->dp_step_no = 0;
     if (h->dp_collective == FNN_DP_COLLECTIVE_P2P) h->dp_collective = FNN_DP_COLLECTIVE_CALLBACK;
 }
@@ -1308,6 +1312,9 @@ int fnn_dp_p2p_export(fnn_handle* h, void* handle64_out, int same_process)
     if (!h->xr_kind) FAIL(h, FNN_ERR_NOMEM, "fnn_dp_p2p_export: no uncached / fine-grained device memory for the exchange region");
     h->xr = static_cast<float*>(q);
     HIPCHK(h, hipMemset(h->xr, 0, h->xr_bytes));
+    if (!h->p2p_wait_max) HIPCHK(h, hipMalloc((void**)&h->p2p_wait_max, 8));
+    HIPCHK(h, hipMemset(h->p2p_wait_max, 0, 8));
+    if (const char* ev2 = getenv("FNN_P2P_TIMEOUT_MS")) { const long long ms = atoll(ev2); if (ms > 0) h->p2p_timeout_ticks = (unsigned long long)ms * 100000ull; }
     h->xr_same_process = same_process != 0;
     memset(handle64_out, 0, 64);
     if (same_process) memcpy(handle64_out, &h->xr, sizeof(void*));
@@ -1347,6 +1354,19 @@ int fnn_dp_set_collective(fnn_handle* h, int collective)
     if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_set_collective inside a step");
     if (collective == FNN_DP_COLLECTIVE_P2P && !(h->dp && h->p2p_attached)) FAIL(h, FNN_ERR_STATE, "FNN_DP_COLLECTIVE_P2P needs fnn_dp_p2p_export + fnn_dp_p2p_attach on every rank first");
     h->dp_collective = collective;
+    return FNN_OK;
+}
+
+int fnn_dp_p2p_max_wait_us(fnn_handle* h, double* us_out)
+{
+    if (!h || !us_out) return FNN_ERR_ARG;
+    *us_out = 0.0;
+    if (!h->p2p_wait_max) return FNN_OK;
+    HIPCHK(h, hipSetDevice(h->dev));
+    unsigned long long t = 0;
+    HIPCHK(h, hipMemcpyAsync(&t, h->p2p_wait_max, 8, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    *us_out = (double)t / 100.0;
     return FNN_OK;
 }
 

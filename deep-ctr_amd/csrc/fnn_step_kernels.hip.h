@@ -311,8 +311,9 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
 //   1. block 0, lane p: release at system scope (this rank's bucket of the step -- written by the launch before this one -- is
 //      visible to every device), then store the step number into flag[rank] of PEER p's region;
 //   2. every block, lane p: poll flag[p] of its OWN region (acquire, system scope) until it holds this step's number -- peer p
-//      has published; bounded (~1 s): a peer that never arrives raises bit 4 of the error word and the block leaves without
-//      touching the weights;
+//      has published; bounded by the clock (default 30 s, $FNN_P2P_TIMEOUT_MS: a first version counted ~2.5 s of polls, which a peer
+//      process that was merely late at start-up could exceed -- met in a two-process rehearsal): a peer that never arrives raises
+//      bit 4 of the error word and the block leaves without touching the weights;
 //   3. sum the world's buckets in RANK order (every rank forms the same sum, bit for bit) and apply
 //      theta <- theta - lr * (sum + L2 term) with the shadow refresh of k_update.
 // Reuse of a parity buffer is safe without a second signal: a rank rewrites bucket[n & 1] in step n + 2, after its step n + 1
@@ -321,6 +322,8 @@ static __global__ __launch_bounds__(256) void k_step3(const SortArgs so, const T
 // ------------------------------------------------------------------------------------------
 struct P2PArgs {
     float* peer[8]; int world, rank; unsigned long long step; size_t bucket_off, flag_off; int* err;
+    unsigned long long timeout_ticks;      // of the constant 100 MHz clock (s_memrealtime): how long a workgroup waits for a peer's flag
+    unsigned long long* wait_max;          // the longest wait any step has seen so far (block 0's pollers), same clock: a diagnostic
 };
 
 template <typename T>
@@ -339,11 +342,12 @@ static __global__ __launch_bounds__(256) void k_p2p_update(const P2PArgs pa, flo
     __syncthreads();
     if (tid < pa.world) {                                       // one wave per workgroup polls (and performs the system-scope acquire)
         const unsigned long long* f = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(pa.peer[pa.rank]) + pa.flag_off) + (size_t)tid * 8;
-        int tries = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < pa.step) {
-            if (++tries > (1 << 21)) { s_bad = 1; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > pa.timeout_ticks) { s_bad = 1; break; }
             __builtin_amdgcn_s_sleep(8);
         }
+        if (blockIdx.x == 0) atomicMax(pa.wait_max, __builtin_amdgcn_s_memrealtime() - t0);
     }
     __syncthreads();                                            // the other waves read the buckets behind this barrier
     if (s_bad) { if (tid == 0) atomicOr(pa.err, 16); return; }

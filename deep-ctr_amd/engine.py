@@ -346,6 +346,11 @@ class FNNEngine(object):
     def dp_set_collective(self, name):
         self._ck(self.lib.fnn_dp_set_collective(self.h, _capi.FNN_DP_COLLECTIVE_P2P if name == 'p2p' else _capi.FNN_DP_COLLECTIVE_CALLBACK))
 
+    def dp_p2p_max_wait_us(self):
+        us = C.c_double(0.0)
+        self._ck(self.lib.fnn_dp_p2p_max_wait_us(self.h, C.byref(us)))
+        return us.value
+
     def dp_config(self):
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._ck(self.lib.fnn_dp_get_config(self.h, C.byref(a), C.byref(b), C.byref(c)))

@@ -216,8 +216,8 @@ int fnn_dp_set_payload(fnn_handle* h, int payload);
  * every rank calls fnn_dp_p2p_attach with all `world` handles in rank order (its own included), then
  * fnn_dp_set_collective(h, FNN_DP_COLLECTIVE_P2P).  same_process != 0: the ranks are handles of ONE process (tests): a
  * "handle" then holds the region's device pointer in its first 8 bytes and nothing is opened.
- * A peer that does not arrive within ~1 s makes the step fail (fnn_sync / the next host read returns FNN_ERR_HIP) instead
- * of hanging; the dense tensors of that step are left untouched. */
+ * A peer that does not arrive within $FNN_P2P_TIMEOUT_MS (default 30 s) makes the step fail (fnn_sync / the next host read returns
+ * FNN_ERR_HIP) instead of hanging; the dense tensors of that step are left untouched. */
 #define FNN_DP_COLLECTIVE_CALLBACK 0
 #define FNN_DP_COLLECTIVE_P2P      1
 int fnn_dp_p2p_export(fnn_handle* h, void* handle64_out, int same_process);
@@ -226,6 +226,9 @@ int fnn_dp_set_collective(fnn_handle* h, int collective);
 /* What is in force: payload, collective, and the kind of memory the exchange region lives in (0 none, 1 uncached,
  * 2 fine-grained, 3 plain hipMalloc). */
 int fnn_dp_get_config(fnn_handle* h, int* payload, int* collective, int* region_kind);
+/* FNN_DP_COLLECTIVE_P2P diagnostic: the longest time (microseconds) the update launch of any step so far has waited for a peer's
+ * flag (rank skew + the flag's way over the fabric).  The wait is bounded by $FNN_P2P_TIMEOUT_MS (default 30,000).  Synchronises. */
+int fnn_dp_p2p_max_wait_us(fnn_handle* h, double* us_out);
 
 /* Portable form, for a caller that issues the collective itself between two calls: _begin runs everything except the
  * dense SGD and leaves the dense gradients (sum over this rank's examples) in one flat f32

@@ -434,10 +434,12 @@ def test_a_rank_on_the_layer_by_layer_path_pairs_with_fast_peers(built, form, wh
             assert np.abs(state[0][1][only0] - ref_rows[only0]).max() <= 3e-4 * change + 1e-7
 
 
-def test_p2p_missing_peer_fails_loudly_and_leaves_the_weights(built):
-    """A peer that never reaches the step: the update launch gives up after ~2^21 polls, raises the error word, and the dense
-    tensors keep their values; the next host read reports FNN_ERR_HIP instead of hanging."""
+def test_p2p_missing_peer_fails_loudly_and_leaves_the_weights(built, monkeypatch):
+    """A peer that never reaches the step: the update launch gives up when its clock-bounded wait runs out ($FNN_P2P_TIMEOUT_MS,
+    1.5 s here, 30 s by default), raises the error word, and the dense tensors keep their values; the next host read reports
+    FNN_ERR_HIP instead of hanging."""
     from deep_ctr_amd.engine import FNNError
+    monkeypatch.setenv('FNN_P2P_TIMEOUT_MS', '1500')
     rows, fo, ids, y, p, r1, r2 = make_problem(300, seed=93)
     ranks = [make_engine(rows, fo, p) for _ in range(2)]
     for r, e in enumerate(ranks):
