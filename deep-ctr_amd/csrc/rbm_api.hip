@@ -300,6 +300,86 @@ __global__ __launch_bounds__(256) void k_rbm_apply(float* __restrict__ W, float*
     }
 }
 
+// k_rbm_batch<true> for S = 32 (the reference's shape) with the online kernel's instruction diet (k_rbm_sparse32): ids and values of
+// the example as scalars (v_readlane), 32 unconditional row gathers, no per-element branch.  Measured at M = 4096, H = 200:
+// the generic body 60 us per mini-batch, this one in profiles/r03c_rbm_kernel_stats.csv.
+__global__ __launch_bounds__(256) void k_rbm_batch32(const BatchArgs a)
+{
+    __shared__ float s_w[32][257];
+    __shared__ float s_hs[256];
+    __shared__ __align__(16) float s_vis[32];
+    __shared__ float s_e[32];
+    const int tid = threadIdx.x, lane = tid & 63, H = a.H;
+    const bool act = tid < H;
+    const int col = act ? tid : 0;                          // idle threads (H < 256) shadow column 0 and never store
+    if (blockIdx.x == 0 && tid == 0) *a.owner_cnt = 0;
+    const float hb = act ? a.hidbias[tid] : 0.f;
+    float wsum[32], hacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) wsum[j] = 0.f;
+    const int jj = tid >> 3, seg = tid & 7;                 // 8 lanes reduce visible jj
+    double err = 0.0;
+    for (int n = blockIdx.x; n < a.M; n += gridDim.x) {
+        const int idv = a.vid[(size_t)n * 32 + (lane & 31)];
+        const float vv = (float)a.vval[(size_t)n * 32 + (lane & 31)];
+        const float u = act ? a.unif[(size_t)n * H + tid] : 2.f;
+        const int my_id = __shfl(idv, jj & 31);
+        const float my_v = __shfl(vv, jj & 31);
+        const float my_vb = a.visbias[my_id];
+        int id[32]; float v[32], wc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            id[j] = __builtin_amdgcn_readlane(idv, j);
+            v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), j));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wc[j] = a.W[(size_t)id[j] * H + col];
+        float z = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z = fmaf(v[j], wc[j], z);
+        const float hid = sigm(z);
+        s_hs[tid] = act ? ((u < hid) ? 1.0f : floorf(hid)) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_w[j][tid] = wc[j];
+        __syncthreads();
+        {
+            float acc = 0.f;
+            for (int i = seg; i < H; i += 8) acc = fmaf(s_hs[i], s_w[jj][i], acc);
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            if (seg == 0) {
+                const float vj = sigm(acc + my_vb);
+                s_vis[jj] = vj;
+                const float d = vj - my_v;
+                s_e[jj] = d * d;
+                a.visbuf[(size_t)n * 32 + jj] = vj;
+            }
+        }
+        __syncthreads();
+        float vis[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(s_vis + 4 * q);
+            vis[4 * q] = t4.x; vis[4 * q + 1] = t4.y; vis[4 * q + 2] = t4.z; vis[4 * q + 3] = t4.w;
+        }
+        float z2 = hb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) z2 = fmaf(vis[j], wc[j], z2);
+        const float hid2 = sigm(z2);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wsum[j] += ((v[j] * hid - vis[j] * hid2) - a.wcost * wc[j]) * a.r_w;
+        if (act) { a.hbuf[((size_t)n * 2) * H + tid] = hid; a.hbuf[((size_t)n * 2 + 1) * H + tid] = hid2; }
+        hacc += hid - hid2;
+        if (tid == 0) { float e = 0.f; for (int j = 0; j < 32; ++j) e += s_e[j]; err += (double)e; }
+        __syncthreads();
+    }
+    if (act) {
+        a.part_h[(size_t)blockIdx.x * H + tid] = hacc;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a.part_w[((size_t)blockIdx.x * 32 + j) * H + tid] = wsum[j];
+    }
+    if (tid == 0) a.part_e[blockIdx.x] = err;
+}
+
 // ---- the row update of a mini-batch WITHOUT atomics (round 3).  The (row, entry) pairs of the mini-batch -- entry = e * S + j, in
 // example order -- are sorted by row with the library's stable radix sort (metrics.hip: the whole epoch's mini-batches are grouped
 // ahead, a few launches per 16 mini-batches), so a row's entries are one run of `rec`, in example order.  A thread owns a 16-byte
@@ -788,7 +868,8 @@ static int sparse_batch_impl(float* W, float* dW, float* visbias, float* dvis, f
                     momentum, part_w, part_h, part_e, hbuf, visbuf, nullptr};
         if (sorted) {
             a.owner_cnt = owner_cnt;                               // zeroed by workgroup 0 of the compute launch (a fill launch costs 4.6 us)
-            hipLaunchKernelGGL(k_rbm_batch<true>, dim3(nwg), dim3(256), 0, st, a);
+            if (S == 32 && !getenv("RBM_BATCH_GENERIC")) hipLaunchKernelGGL(k_rbm_batch32, dim3(nwg), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_rbm_batch<true>, dim3(nwg), dim3(256), 0, st, a);
             RbmScatArgs sa{rec_mb, seg_n, hbuf, visbuf, vval + n0 * S, wstep, W, visbias, H, S, weightcost, rate_vis, rate_w, momentum,
                            spart, owners, owner_cnt};
             const long nthr = (long)nchunk * (H / 4);

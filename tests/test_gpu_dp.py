@@ -305,13 +305,14 @@ def test_two_virtual_ranks_exchange_keeps_replicas_identical(built):
         e.close()
 
 
-def test_scatter_global_at_eight_times_4096(built):
+@pytest.mark.parametrize("Bg", [32768, 20000])
+def test_scatter_global_at_eight_times_4096(built, Bg):
     """BASELINE configs[3] in the exact mode: a global batch of 8 x 4096 = 32,768 examples.  fnn_step_scatter_global (rocPRIM
     grouping beyond 16,384 keys per field) must leave the table the float64 oracle's sequential update leaves, given the
     same slot gradients: hot rows of the small fields are hit thousands of times (decay powers up to c^32768)."""
     import torch
     from oracle import fnn_oracle as orc
-    Bg = 32768
+    # (20,000: a global batch that does not fill its power-of-two segment -- 12,768 invalid entries per field sort behind the rows)
     sizes = synth.field_sizes_tiny(3000)
     rows = synth.fm_table(sum(sizes), K, 0.05, 5)
     fo = synth.field_of_row(sizes)

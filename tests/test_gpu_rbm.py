@@ -277,3 +277,61 @@ def test_sparse_minibatch_data_parallel_two_virtual_ranks(built, tmp_path):
             np.testing.assert_allclose(W0.cpu().numpy()[only0], W.cpu().numpy()[only0], rtol=1e-6, atol=1e-9)
             only1 = np.array(sorted(rows[1] - rows[0]), np.int64)
             assert torch.equal(W0[only1], torch.as_tensor(ost.W.astype(np.float32)).to(dev)[only1])    # rank 0 never moved them
+
+
+@pytest.mark.parametrize("H,S,M,N", [(8, 16, 37, 100), (256, 32, 50, 120), (200, 32, 300, 300), (40, 5, 7, 30)])
+def test_sparse_minibatch_edge_shapes(built, H, S, M, N):
+    """The sorted row update at the edges: fewer than 32 visibles per example, the widest hidden layer, a short LAST mini-batch
+    (N not a multiple of M: invalid entries in the sorted segment), all examples in one mini-batch, ids that repeat inside a
+    mini-batch across different positions (the grouping is by row over the whole mini-batch, not per position) -- against the
+    float64 mini-batch oracle; two runs bit-identical."""
+    import ctypes as C
+    import torch
+    from deep_ctr_amd import _capi
+    lib = _capi.load()
+    rng = np.random.RandomState(H + S + M)
+    n_rows = 400
+    # S distinct sorted ids per example out of few rows: heavy repetition across examples, at any position
+    vid = np.stack([np.sort(rng.choice(60 if S <= 16 else n_rows, size=S, replace=False)) for _ in range(N)]).astype(np.int32)
+    vval = (rng.uniform(size=(N, S)) < 0.5).astype(np.uint8)
+    W0 = rng.uniform(-0.1, 0.1, (n_rows, H)); vb0 = rng.uniform(-0.1, 0.1, n_rows); hb0 = rng.uniform(-0.1, 0.1, H)
+    ws0 = rng.uniform(-1e-3, 1e-3, (S, H))
+    unif = rng.uniform(size=(N, H))
+    Wi = W0.astype(np.float32).astype(np.float64)
+
+    class Replay(object):
+        def __init__(self):
+            self.i = 0
+
+        def uniform(self, size=None):
+            self.i += 1
+            return unif.astype(np.float32).astype(np.float64)[self.i - 1].reshape(size)
+    dev = torch.device('cuda', 0)
+    stm = torch.cuda.current_stream(dev).cuda_stream
+    runs = []
+    for _ in range(2):
+        t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dt).contiguous()      # noqa: E731
+        Wd, vb, hb, ws = t(W0), t(vb0), t(hb0), t(ws0)
+        dW, dvis = torch.zeros_like(Wd), torch.zeros_like(vb)
+        vd, vv, ud = t(vid, torch.int32), t(vval, torch.uint8), t(unif)
+        err = C.c_double()
+        rc = lib.rbm_sparse_batch(Wd.data_ptr(), dW.data_ptr(), vb.data_ptr(), dvis.data_ptr(), hb.data_ptr(), ws.data_ptr(), vd.data_ptr(),
+                                  vv.data_ptr(), ud.data_ptr(), N, M, H, S, 2e-4, 1e-2, 1e-2, 1e-2, 0.9, C.byref(err), stm)
+        assert rc == 0, lib.rbm_last_error()
+        runs.append((Wd.cpu().numpy(), vb.cpu().numpy(), hb.cpu().numpy(), ws.cpu().numpy(), err.value))
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)
+    W, vbg, hbg, wsg, e = runs[0]
+    # rates 1e-2 (100x the reference's) so that the updates stand clear of f32 round-off
+    ref_rates = dict(weightcost=0.0002, rates=(1e-2, 1e-2, 1e-2))
+    st2 = ro.SparseRBMState(n_rows, H, S, np.random.RandomState(0))
+    st2.W, st2.visbias, st2.hidbias, st2.weightstep = Wi.copy(), vb0.astype(np.float32).astype(np.float64), hb0.astype(np.float32).astype(np.float64), \
+        ws0.astype(np.float32).astype(np.float64)
+    rp2, e2 = Replay(), 0.0
+    for n0 in range(0, N, M):
+        e2 += ro.sparse_cd1_minibatch(st2, [(list(vid[n]), vval[n].astype(np.float64)) for n in range(n0, min(N, n0 + M))], rp2, **ref_rates)
+    assert rel_change_err(W.astype(np.float64), st2.W, Wi) < 2e-3
+    np.testing.assert_allclose(wsg, st2.weightstep, rtol=2e-3, atol=1e-8)
+    assert np.abs(hbg - st2.hidbias).max() <= 2e-3 * np.abs(st2.hidbias - hb0).max() + 1e-7
+    assert np.abs(vbg - st2.visbias).max() <= 2e-3 * np.abs(st2.visbias - vb0).max() + 1e-7
+    assert abs(e - e2) <= 1e-4 * e2
