@@ -377,6 +377,10 @@ template <typename T> struct StripFwdArgs {
     // strips on every CU).  has_out = 0: the last product of this launch is a hidden layer whose tile leaves for HBM in the F layout
     // (finalF: the next launch's a0), block by block as it is computed -- no swap, no barrier behind it.
     int has_out; T* finalF;
+    // 16-example strips (RT = 1) only: products whose weights are copied into LDS behind the two tiles at the start of the launch
+    // (element offset there, or -1: streamed from L2 as usual).  The narrow products are chains of a few k-steps, each an L2 round
+    // trip long (~600 ticks with four in flight); from LDS a k-step costs what its MFMAs cost
+    int wlds[STRIP_MAXP];
 };
 template <typename T> struct StripBwdArgs {
     const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
@@ -388,6 +392,7 @@ template <typename T> struct StripBwdArgs {
     // bottom = 1: product 1 of this launch is the stack's first (its output is dz1, f32, no tile).  bottom = 0: the launch stops inside
     // the stack and product 1's tile leaves for HBM in the F layout (finalF: the next launch's dlast)
     int bottom; T* finalF;
+    int wlds[STRIP_MAXP];                                        // as in StripFwdArgs (index = product index t - 1 of this launch)
 };
 
 // one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
@@ -627,6 +632,7 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     extern __shared__ __align__(16) unsigned char strip_smem[];
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
+    T* wl = out + (size_t)RT * 16 * maxD;                        // RT = 1: LDS copies of the small products' weights (a.wlds)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = a.duo.on ? (int)(blockIdx.x & 1) : 0, sidx = a.duo.on ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     const int row0 = sidx * RT * 16;
@@ -642,10 +648,21 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     auto prefetch_next = [&]() {
         if (nx.p < a.n && nx.p <= last) {
             bool sp; int cn; blocks(nx.p, sp, cn);
-            strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            const int wo = RT == 1 ? a.wlds[nx.p] : -1;
+            // (spelled from the LDS array itself: through the captured pointer the address space was lost and the loads came out flat_)
+            if (wo >= 0) strip_prefetch<T>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            else strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
         }
     };
-    prefetch_next();
+    if (RT == 1) {                                               // the small products' weights -> LDS (contiguous, fragment-tiled: offsets carry over)
+        const bool first_lds = nx.p < a.n && a.wlds[nx.p] >= 0;
+        if (!first_lds) prefetch_next();                         // a first item streamed from L2 (the big first product) does not wait for the copy
+        bool any = false;
+        for (int p = 0; p < a.n; ++p)
+            if (a.wlds[p] >= 0) { strip_load<T>(wl + a.wlds[p], a.W[p], a.Dp[p] * a.Dp[p + 1] / EPL); any = true; }
+        if (any) lds_barrier();                                  // (uniform: `any` comes from the arguments)
+        if (first_lds) prefetch_next();
+    } else prefetch_next();
     // the strip of a0: row tiles RT sidx .. of an F-layout operand are contiguous
     strip_load<T>(in, a.a0 + (size_t)sidx * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
     lds_barrier();
@@ -667,7 +684,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 if (a.duo.on && !split && h == 1) ef.outT = nullptr;     // (not reached: the second workgroup computes split products only)
                 typename EpiIpFwd<T>::Aux ax[RT][4];
                 strip_aux<T, RT>(ax, ef, row0, blk, lane);
-                strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
+                else strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 DET(11);
                 nx = strip_next(a, nx, wave, true, h);
                 prefetch_next();
@@ -677,7 +695,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 if (fin) { if (split || h == 0) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane); }
                 else if (split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
             } else {                                              // the output unit: logits, loss, delta (column 0)
-                strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
+                else strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 nx.p = a.n;
                 const EpiIpOut<T> eo = a.eo;
                 const int rq = 4 * (lane >> 4), cl = lane & 15;
@@ -715,6 +734,7 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     const int row0 = sidx * RT * 16;
     STRIP_STAMP(0);
     if (a.dbg && threadIdx.x == 0) { for (int i = 10; i < 16; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = 0; }
+    T* wl = out + (size_t)RT * 16 * maxD;                        // RT = 1: LDS copies of the small products' weights (a.wlds)
     StripB<T> pb;                                                 // item index q = n - t: product t = n - q
     StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false, h);
     const int rot = (a.rot == 1) ? (sidx >> 3) : (a.rot == 2 ? sidx : 0);   // workgroups g, g + 8, ... share an XCD
@@ -722,9 +742,17 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     auto prefetch_next = [&]() {
         if (nx.p < a.n) {
             bool sp; int cn; blocks(nx.p, sp, cn);
-            strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            const int wo = RT == 1 ? a.wlds[a.n - nx.p - 1] : -1;
+            if (wo >= 0) strip_prefetch<T>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            else strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
         }
     };
+    if (RT == 1) {                                               // the small products' weights -> LDS; in the backward launch they are the FIRST products
+        bool any = false;
+        for (int p = 0; p < a.n; ++p)
+            if (a.wlds[p] >= 0) { strip_load<T>(wl + a.wlds[p], a.W[p], a.Dp[p] * a.Dp[p + 1] / EPL); any = true; }
+        if (any) lds_barrier();                                  // the first item's prefetch reads them
+    }
     prefetch_next();
     strip_load<T>(in, a.dlast + (size_t)sidx * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
     lds_barrier();
@@ -740,7 +768,8 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
             if (a.duo.on && !split && h == 1) { eb.outT = nullptr; eb.out32 = nullptr; }   // a narrow product of a pair: both compute it, the first one stores it
             typename EpiIpBwd<T>::Aux ax[RT][4];
             strip_aux<T, RT>(ax, eb, row0, blk, lane);
-            strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
+            if (RT == 1 && a.wlds[t - 1] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[t - 1], nkt, blk, lane);
+            else strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
             nx = strip_next(a, nx, wave, false, h);
             prefetch_next();
             strip_epilogue<T, RT>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
@@ -1030,6 +1059,8 @@ template <typename T> void ip_refresh(ipnn_handle* h, int t, const float* slab, 
                        h->slab_stride, lr, Din, Dout, (T*)h->wf[t - 1], (T*)h->wb[t - 1]);
 }
 
+inline int maxD2x(const int* Dp, int n) { int m = 0; for (int t = 0; t <= n; ++t) m = std::max(m, Dp[t]); return m; }
+
 template <typename T>
 int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* const* masks, float* logits_out,
            float* p_out, bool train)
@@ -1124,8 +1155,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->strip_attr = true;
         }
     }
@@ -1135,6 +1166,19 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     // (the second workgroup of a pair has nothing to do there).  They run as 16-example strips instead: 256 workgroups, one per CU, no
     // pairs; the wide products keep the pairs of 32-example strips.  The hand-over is the tile of layer `cut` in the F layout (a[cut]
     // forward, dl[cut - 1] backward), written block by block by the waves that computed it.
+    // small products of a 16-example-strip launch whose weights go to LDS behind the tiles: each up to 64 KB, all of them within what is
+    // left of 152 KB (IPNN_TAIL_LDS=0: none); returns the bytes they take, fills the element offsets
+    const int tail_w_lds = getenv("IPNN_TAIL_LDS") ? atoi(getenv("IPNN_TAIL_LDS")) : 1;
+    auto lds_weights = [&](const int* Dp, int n, int* wlds) -> size_t {
+        size_t used = 0;
+        const size_t budget = (size_t)152 * 1024 > (size_t)2 * 16 * maxD2x(Dp, n) * sizeof(T) ? (size_t)152 * 1024 - (size_t)2 * 16 * maxD2x(Dp, n) * sizeof(T) : 0;
+        for (int p = 0; p < n; ++p) {
+            const size_t b = (size_t)Dp[p] * Dp[p + 1] * sizeof(T);
+            if (tail_w_lds && b <= 64 * 1024 && used + b <= budget) { wlds[p] = (int)(used / sizeof(T)); used += b; }
+            else wlds[p] = -1;
+        }
+        return used;
+    };
     int cut = L;
     while (cut >= 1 && h->Dp[cut] / 64 < h->duo_min) --cut;
     const bool tsplit = strip && duo && h->tail_split && cut >= 1 && cut < L;
@@ -1154,6 +1198,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                             logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         sa.dbg = h->stamps; sa.rot = h->strip_rot; sa.sel = getenv("IPNN_STAMP_SEL") ? atoi(getenv("IPNN_STAMP_SEL")) : -1;
         sa.has_out = 1; sa.finalF = nullptr;
+        for (int t = 0; t < STRIP_MAXP; ++t) sa.wlds[t] = -1;
         if (!tsplit) {
             sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
             hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sa, maxD);
@@ -1169,7 +1214,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             for (int t = cut + 1; t <= L; ++t) s2.ef[t - cut - 1] = sa.ef[t - 1];
             s2.eo = sa.eo; s2.dbg = nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr;
             s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
-            hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds, h->st, s2, maxD2);
+            const size_t wl2 = lds_weights(s2.Dp, s2.n, s2.wlds);
+            hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
         }
     } else {
     IpProf ps(h, "fwd");
@@ -1199,6 +1245,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         }
         sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
         sb.bottom = 1; sb.finalF = nullptr;
+        for (int t = 0; t < STRIP_MAXP; ++t) sb.wlds[t] = -1;
         if (!tsplit) {
             sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
             hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * (duo ? 2 : 1)), dim3(64 * STRIP_NW), strip_lds, h->st, sb, maxD);
@@ -1209,7 +1256,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             for (int t = cut + 1; t <= L + 1; ++t) { sA.W[t - cut - 1] = sb.W[t - 1]; sA.eb[t - cut - 1] = sb.eb[t - 1]; }
             sA.dbg = nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1];
             sA.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
-            hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds, h->st, sA, maxD2);
+            const size_t wlA = lds_weights(sA.Dp, sA.n, sA.wlds);
+            hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
             StripBwdArgs<T> sB = sb;                                  // products cut .. 1: pairs of 32-example strips, from delta l_cut in HBM
             sB.dlast = (const T*)h->dl[cut - 1]; sB.n = cut;
             sB.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};

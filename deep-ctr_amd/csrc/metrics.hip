@@ -108,16 +108,24 @@ __global__ __launch_bounds__(256) void k_rs_hist(const unsigned long long* __res
         if (i < n) atomicAdd(&s_h[(unsigned)(seg[i] >> shift) & 255u], 1u);          // LDS integer atomics: counts, order-free
     }
     __syncthreads();
-    hist[((size_t)blockIdx.y * 256 + threadIdx.x) * nblk + blockIdx.x] = s_h[threadIdx.x];
+    hist[((size_t)blockIdx.y * nblk + blockIdx.x) * 256 + threadIdx.x] = s_h[threadIdx.x];       // [segment][tile][digit]: a wave's 64 digits are one line
 }
 
-// one workgroup per segment, thread = digit: counts [digit][tile] -> exclusive prefix in (digit, tile) order
+// one workgroup per segment, thread = digit: counts [tile][digit] -> exclusive prefix in (digit, tile) order.  A thread's counts are
+// 1 KB apart, a wave's 64 digits one line of a tile; eight tiles' loads in flight at a time (one load, one add per trip paid a
+// memory round trip per tile: 26 us per pass at 64 tiles, profiles/r03c_rbm_kernel_stats.csv)
 __global__ __launch_bounds__(256) void k_rs_scan(unsigned* __restrict__ hist, int nblk)
 {
     __shared__ unsigned s_t[256];
-    unsigned* h = hist + ((size_t)blockIdx.x * 256 + threadIdx.x) * nblk;
+    unsigned* h = hist + (size_t)blockIdx.x * nblk * 256 + threadIdx.x;
     unsigned tot = 0;
-    for (int b = 0; b < nblk; ++b) tot += h[b];
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = b0 + k < nblk ? h[(size_t)(b0 + k) * 256] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += v[k];
+    }
     s_t[threadIdx.x] = tot;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {                       // inclusive scan over the 256 digit totals
@@ -127,7 +135,13 @@ __global__ __launch_bounds__(256) void k_rs_scan(unsigned* __restrict__ hist, in
         __syncthreads();
     }
     unsigned run = s_t[threadIdx.x] - tot;
-    for (int b = 0; b < nblk; ++b) { const unsigned c = h[b]; h[b] = run; run += c; }
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = b0 + k < nblk ? h[(size_t)(b0 + k) * 256] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (b0 + k < nblk) { h[(size_t)(b0 + k) * 256] = run; run += v[k]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_rs_scatter(const unsigned long long* __restrict__ keys_in, unsigned long long* __restrict__ keys_out,
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const unsigned long long* __
     unsigned long long* out = keys_out + (size_t)blockIdx.y * n;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_cnt[w][tid] = 0;
-    s_base[tid] = hist[((size_t)blockIdx.y * 256 + tid) * nblk + blockIdx.x];
+    s_base[tid] = hist[((size_t)blockIdx.y * nblk + blockIdx.x) * 256 + tid];
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + wave * (RS_TILE / 4);
     const unsigned long long lt = (1ull << lane) - 1ull;
