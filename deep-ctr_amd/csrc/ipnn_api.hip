@@ -1028,6 +1028,7 @@ struct ipnn_handle {
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
+    bool stamp_tail = false;                         // IPNN_STAMPS=2: the stamps of the 16-example-strip launches instead of the wide ones
     int tail_split = 1;                              // IPNN_TAIL_SPLIT=0: the whole stack in one strip launch per direction (round 2's form)
     bool duo_failed = false;                         // a pair gave up once: every later train step is refused until the handle is re-created
     bool gemm_lds = false;                           // IPNN_GEMM_LDS=1: LDS-staged k_gemm_lds for the wide products (measured equal to k_gemm_ft: both L2-bound)
@@ -1168,7 +1169,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     // forward, dl[cut - 1] backward), written block by block by the waves that computed it.
     // small products of a 16-example-strip launch whose weights go to LDS behind the tiles: each up to 64 KB, all of them within what is
     // left of 152 KB (IPNN_TAIL_LDS=0: none); returns the bytes they take, fills the element offsets
-    const int tail_w_lds = getenv("IPNN_TAIL_LDS") ? atoi(getenv("IPNN_TAIL_LDS")) : 1;
+    // Measured (profiles/r03d_ipnn_tail_lds_ab.json, A/B on one box): with the 88 KB copy 0.2700 / 0.2704 ms per step against 0.2629 /
+    // 0.2667 without -- the copy costs more than the k-steps it shortens (the tails are not bound by their weight fetches): OFF by default
+    const int tail_w_lds = getenv("IPNN_TAIL_LDS") ? atoi(getenv("IPNN_TAIL_LDS")) : 0;
     auto lds_weights = [&](const int* Dp, int n, int* wlds) -> size_t {
         size_t used = 0;
         const size_t budget = (size_t)152 * 1024 > (size_t)2 * 16 * maxD2x(Dp, n) * sizeof(T) ? (size_t)152 * 1024 - (size_t)2 * 16 * maxD2x(Dp, n) * sizeof(T) : 0;
@@ -1206,14 +1209,15 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             StripFwdArgs<T> s1 = sa;                                  // products 1 .. cut: pairs of 32-example strips; a[cut] -> HBM
             s1.n = cut; s1.has_out = 0; s1.finalF = (T*)h->a[cut];
             s1.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
-            hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
             StripFwdArgs<T> s2{};                                     // products cut + 1 .. L + 1: 16-example strips, every CU
             s2.a0 = (const T*)h->a[cut]; s2.n = L + 1 - cut;
             for (int t = cut; t <= L + 1; ++t) s2.Dp[t - cut] = h->Dp[t];
             for (int t = cut + 1; t <= L + 1; ++t) s2.W[t - cut - 1] = sa.W[t - 1];
             for (int t = cut + 1; t <= L; ++t) s2.ef[t - cut - 1] = sa.ef[t - 1];
-            s2.eo = sa.eo; s2.dbg = nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr;
+            s2.eo = sa.eo; s2.dbg = h->stamp_tail ? h->stamps : nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr;
+            if (h->stamp_tail) s1.dbg = nullptr;
             s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
+            hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
             const size_t wl2 = lds_weights(s2.Dp, s2.n, s2.wlds);
             hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
         }
@@ -1254,12 +1258,13 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             sA.dlast = (const T*)h->dl[L]; sA.n = L + 1 - cut;
             for (int t = cut; t <= L + 1; ++t) sA.Dp[t - cut] = h->Dp[t];
             for (int t = cut + 1; t <= L + 1; ++t) { sA.W[t - cut - 1] = sb.W[t - 1]; sA.eb[t - cut - 1] = sb.eb[t - 1]; }
-            sA.dbg = nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1];
+            sA.dbg = h->stamp_tail ? sb.dbg : nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1];
             sA.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
             const size_t wlA = lds_weights(sA.Dp, sA.n, sA.wlds);
             hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
             StripBwdArgs<T> sB = sb;                                  // products cut .. 1: pairs of 32-example strips, from delta l_cut in HBM
             sB.dlast = (const T*)h->dl[cut - 1]; sB.n = cut;
+            if (h->stamp_tail) sB.dbg = nullptr;
             sB.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
             hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, sB, maxD);
         }
@@ -1465,7 +1470,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(hipMalloc((void**)&h->ref0, ref.size() * 4));
         IK(hipMemcpy(h->ref0, ref.data(), ref.size() * 4, hipMemcpyHostToDevice));
     }
-    if (getenv("IPNN_STAMPS")) IK(al((void**)&h->stamps, (size_t)2 * (h->ldT / 16) * 16 * 8));
+    if (getenv("IPNN_STAMPS")) { IK(al((void**)&h->stamps, (size_t)2 * (h->ldT / 16) * 16 * 8)); h->stamp_tail = atoi(getenv("IPNN_STAMPS")) == 2; }
     IK(hipStreamSynchronize(h->st));
 #undef IK
     *out = h;
@@ -1690,8 +1695,8 @@ int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms)
     IHK(h, hipStreamSynchronize(h->st));
     *avg_ms = 0.0;
     if (h->stamps && (!strcmp(which, "fwd") || !strcmp(which, "bwd"))) {      // IPNN_STAMPS=1: the last step's per-layer stamps
-        const bool duo = h->duo_xch != nullptr;                    // pairs: even workgroups run the whole stack, odd ones the wide products only
-        const int nwg = h->ldT / (h->bf16 ? 32 : 16) * (duo ? 2 : 1), np = h->L + 3;
+        const bool duo = h->duo_xch != nullptr && !h->stamp_tail;  // pairs: even workgroups run the whole stack, odd ones the wide products only
+        const int nwg = h->stamp_tail ? h->ldT / 16 : h->ldT / (h->bf16 ? 32 : 16) * (duo ? 2 : 1), np = h->L + 3;
         std::vector<long long> st((size_t)nwg * 16);
         IHK(h, hipMemcpy(st.data(), h->stamps + (strcmp(which, "bwd") ? 0 : (size_t)(h->ldT / 16) * 16), st.size() * 8, hipMemcpyDeviceToHost));
         for (int par = 0; par < (duo ? 2 : 1); ++par) {
