@@ -668,7 +668,6 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     lds_barrier();
     STRIP_STAMP(1);
     f32x4 acc[RT][4];
-    typename EpiIpFwd<T>::Aux axn[4]; bool have_axn = false;     // RT = 1: the next item's epilogue inputs, requested one item ahead
     int seq = 0;
     for (int l = 0; l <= last; ++l) {
         const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
@@ -684,26 +683,12 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 EpiIpFwd<T> ef = a.ef[l];                       // the layer's epilogue parameters: scalar registers, loaded once
                 if (a.duo.on && !split && h == 1) ef.outT = nullptr;     // (not reached: the second workgroup computes split products only)
                 typename EpiIpFwd<T>::Aux ax[RT][4];
-                if (RT == 1 && have_axn) {
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) ax[0][n] = axn[n];
-                } else strip_aux<T, RT>(ax, ef, row0, blk, lane);
+                strip_aux<T, RT>(ax, ef, row0, blk, lane);
                 if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
                 else strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
                 DET(11);
                 nx = strip_next(a, nx, wave, true, h);
                 prefetch_next();
-                have_axn = false;
-                if (RT == 1 && nx.p < a.n && nx.p <= last && (!a.has_out || nx.p + 1 < a.n)) {
-                    // 16-example strips: what the NEXT item's epilogue reads from memory (keep-mask bytes) is requested now -- a narrow
-                    // product's k-loop (2-14 k-steps) is too short to hide that round trip (stamped: 8-10 k ticks per narrow product)
-                    bool sp; int cn; blocks(nx.p, sp, cn);
-                    const int bn = strip_phys(sp, nx.blk, cn, h, rot), rq = 4 * (lane >> 4), cl = lane & 15;
-                    const EpiIpFwd<T> en = a.ef[nx.p];
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) axn[n] = en.load(row0 + rq, bn * 64 + n * 16 + cl);
-                    have_axn = true;
-                }
                 DET(12);
                 strip_epilogue<T, RT>(acc, ax, ef, out, N, row0, blk, lane);
                 DET(13);
@@ -773,7 +758,6 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     lds_barrier();
     STRIP_STAMP(1);
     f32x4 acc[RT][4];
-    typename EpiIpBwd<T>::Aux axn[4]; bool have_axn = false;     // RT = 1: the next item's epilogue inputs, requested one item ahead
     int seq = 0;
     for (int t = a.n; t >= 1; --t) {                              // delta l_{t-1} = (delta l_t . W_t^T) * mask * act'
         const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
@@ -783,23 +767,11 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
             EpiIpBwd<T> eb = a.eb[t - 1];
             if (a.duo.on && !split && h == 1) { eb.outT = nullptr; eb.out32 = nullptr; }   // a narrow product of a pair: both compute it, the first one stores it
             typename EpiIpBwd<T>::Aux ax[RT][4];
-            if (RT == 1 && have_axn) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n) ax[0][n] = axn[n];
-            } else strip_aux<T, RT>(ax, eb, row0, blk, lane);
+            strip_aux<T, RT>(ax, eb, row0, blk, lane);
             if (RT == 1 && a.wlds[t - 1] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[t - 1], nkt, blk, lane);
             else strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
             nx = strip_next(a, nx, wave, false, h);
             prefetch_next();
-            have_axn = false;
-            if (RT == 1 && nx.p < a.n) {                          // (as in the forward kernel: the next item's mask bytes and activations, one item ahead)
-                bool sp; int cn; blocks(nx.p, sp, cn);
-                const int bn = strip_phys(sp, nx.blk, cn, h, rot), rq = 4 * (lane >> 4), cl = lane & 15;
-                const EpiIpBwd<T> en = a.eb[a.n - nx.p - 1];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) axn[n] = en.load(row0 + rq, bn * 64 + n * 16 + cl);
-                have_axn = true;
-            }
             strip_epilogue<T, RT>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
             if (split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
             if (t == 1 && !a.bottom && (split || h == 0)) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane);
