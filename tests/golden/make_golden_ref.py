@@ -31,6 +31,9 @@ unchanged, in a namespace that holds only NumPy, linecache and the inputs:
     SNN_RBM.py    :239-256 the line loop of get_fi_h1_y (active features, bag sum, sigmoid),
                   :285-291 THE UPDATE LOOP of mytrain (bb0 / ww0)                                           (A8)
     baseline.py   :262-281 early_stop, :369 / :422 the NDS re-calibration statements                        (row N4, host side)
+    sampling_based_denosing_autoencoder.py   :303-311 the negative-sampling token loop of sparse_da (int(rng.uniform(a, id)) draws),
+                  :165-188 the lower-layer propagation loop of da (the running sum over hidden units, a sigmoid after
+                  every layer)                                                                               (row N2, host side)
 Nothing stands in for Theano: a statement that names `theano` is not executed (get_batch_data's and get_fi_h1_y's final
 `numpy.array(..., dtype=theano.config.floatX)` conversions).  The gradients `gx` those loops consume come from the compiled
 callable in the reference; here they are inputs of the fixture -- random arrays, or (for the fixtures the GPU step is held to)
@@ -61,7 +64,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__)) if '__file__' in globals() else None     # the child runs from text
 REF = '/root/reference/python'
 MODULES = ['data_fm', 'dl_utils', 'ipinyou', 'sampling_based_gaussian_binary_rbm_sparse']
-SCRIPTS = ['FNN_wnzh', 'SNN_RBM', 'baseline']
+SCRIPTS = ['FNN_wnzh', 'SNN_RBM', 'baseline', 'sampling_based_denosing_autoencoder']
 SOURCES = {}                     # name -> text (the child's copy arrives over the pipe)
 
 
@@ -317,6 +320,40 @@ def part2(out, work, demo, given):
         out[tag + '_ww0_after_touched'] = np.array(ns['ww0'], np.float64)[touched]
         out[tag + '_bb0_after'] = np.array(ns['bb0'], np.float64)
 
+    # ================================================================ sampling_based_denosing_autoencoder.py (row N2)
+    tree, path = reference_tree('sampling_based_denosing_autoencoder')
+    tok_loops = [n for n in ast.walk(function(tree, 'sparse_da')) if isinstance(n, ast.For) and ast.unparse(n.iter) == 'range(1, len(s), 2)']
+    assert len(tok_loops) == 1 and 'new_sample' in names_in(tok_loops[0])
+    lines = given['dae_lines']
+    seed = int(given['dae_seed'])
+    rs = np.random.RandomState(seed)
+    xs, idxs = [], []
+    for ln in lines:                                                   # :302-303: s = line.strip().replace(':', ' ').split(' '), x / indexes / a reset per line
+        ns = {'s': ln.strip().replace(':', ' ').split(' '), 'k': 2, 'rng': rs, 'x': [], 'indexes': [], 'a': 0}
+        run_nodes(tok_loops, path, ns)
+        xs.append(ns['x']); idxs.append(ns['indexes'])
+    out['dae_lines'], out['dae_seed'] = np.array(lines), np.int64(seed)
+    out['dae_samp_x'], out['dae_samp_idx'] = pad(xs), pad(idxs)
+    out['dae_next_draw'] = np.float64(rs.random_sample())              # where the stream stands afterwards
+    prop = []                                                          # `i=0` and the `for r in results:` behind it (:164-188; a second copy serves the last batch, :198-222)
+    for parent in ast.walk(function(tree, 'da')):
+        body = getattr(parent, 'body', None)
+        if isinstance(body, list):
+            for k, st in enumerate(body):
+                if isinstance(st, ast.For) and ast.unparse(st.iter) == 'results':
+                    assert k > 0 and ast.unparse(body[k - 1]) == 'i = 0'
+                    prop.append((st.lineno, [body[k - 1], st]))
+    prop = [nodes for _, nodes in sorted(prop, key=lambda x: x[0])]
+    assert len(prop) == 2
+    res_list = [np.array(a, np.float64) for a in given['dae_results']]
+    ns = {'numpy': np, 'np': np, 'results': res_list, 'indexes': [list(r) for r in given['dae_prop_ids']],
+          'batcharr': np.array(given['dae_prop_vals'], dtype=np.float32)}
+    run_nodes(prop[0], path, ns)
+    out['dae_prop_ids'] = pad(given['dae_prop_ids'])
+    for i, a in enumerate(res_list):
+        out['dae_prop_res%d' % i] = a
+    out['dae_prop_out'] = np.array(ns['batcharr'], np.float64)
+
     # ================================================================ baseline.py
     tree, path = reference_tree('baseline')
     es = function(tree, 'early_stop')                                  # :262-281
@@ -464,6 +501,14 @@ def oracle_inputs(demo):
               0.6 + 0.2 * (1 - np.exp(-t / 6.0)) - 0.004 * np.maximum(0, t - 30),
               np.full(T, 0.75),
               rs.uniform(0.5, 0.9, T)]
+    # row N2: the dA module's token loop (negative sampling) on demo lines, and its lower-layer propagation on two lower layers
+    given['dae_lines'] = demo_lines[80:104]
+    given['dae_seed'] = 123
+    rs = np.random.RandomState(35)
+    n_vis = max(fw) + 1
+    given['dae_results'] = [rs.uniform(-0.3, 0.3, (n_vis, 12)), rs.uniform(-0.1, 0.1, 12), rs.uniform(-0.5, 0.5, (12, 7)), rs.uniform(-0.1, 0.1, 7)]
+    given['dae_prop_ids'] = [orc.parse_line(ln)[0] for ln in demo_lines[104:112]]
+    given['dae_prop_vals'] = [[1] * 16 for _ in range(8)]
     given['es_series'] = np.array(series)
     given['es_cfgs'] = [(0, 1, 10, 10), (0, 1, 1, 2), (5, 2, 3, 4), (0, 3, 2, 3), (40, 1, 5, 2), (0, 1, 4, 9)]
     given['nds_p'] = np.concatenate([rs.uniform(0, 1, 29), [0.0, 1.0, 0.5]])

@@ -154,3 +154,25 @@ def test_snn_step_vs_reference_loops(ref, built):
     bupd = np.abs(ref['snn1_bb0_after'] - bb0).max()
     assert np.abs(eng.get_bag_bias() - ref['snn1_bb0_after']).max() <= 1e-3 * bupd + 6e-8 * 0.1
     eng.close()
+
+
+def test_dae_lower_layer_propagation_vs_reference_loop(ref, built):
+    """Row N2: dae_bag_cumsum_sigmoid_f64 (layer 0: the reference's running sum over hidden units, then the sigmoid) and
+    dae_affine_sigmoid_f64 (every further layer) against the output of the reference's own propagation loop
+    (sampling_based_denosing_autoencoder.py:164-188, tests/golden/ref_run.npz dae_prop_*)."""
+    import ctypes as C
+    import torch
+    from deep_ctr_amd import _capi
+    lib = _capi.load()
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    W0, b0, W1, b1 = (torch.as_tensor(ref['dae_prop_res%d' % i]).to(dev).contiguous() for i in range(4))
+    ids = torch.as_tensor(ref['dae_prop_ids'].astype(np.int32)).to(dev).contiguous()
+    n, F = ids.shape
+    H0, H1 = W0.shape[1], W1.shape[1]
+    X = torch.empty((n, H0), dtype=torch.float64, device=dev)
+    assert lib.dae_bag_cumsum_sigmoid_f64(W0.data_ptr(), b0.data_ptr(), H0, W0.shape[0], ids.data_ptr(), n, F, X.data_ptr(), st) == 0, lib.dae_last_error()
+    Y = torch.empty((n, H1), dtype=torch.float64, device=dev)
+    assert lib.dae_affine_sigmoid_f64(X.data_ptr(), W1.data_ptr(), b1.data_ptr(), n, H0, H1, Y.data_ptr(), st) == 0, lib.dae_last_error()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Y.cpu().numpy(), ref['dae_prop_out'], rtol=0, atol=1e-13)

@@ -264,3 +264,28 @@ def test_early_stop_and_recalibration_equal_reference(ref, capsys):
     finally:
         bl.least_step, bl.skip_window, bl.smooth_window, bl.stop_window = saved
     assert 'early stop at step' in capsys.readouterr().out
+
+
+def test_dae_sampling_and_propagation_equal_reference_loops(ref):
+    """Row N2, host side: the token loop of sparse_da (sampling_based_denosing_autoencoder.py:303-311 -- per feature one draw
+    int(rng.uniform(a, id)) of a negative visible, skipped when already present) and the lower-layer propagation loop of da
+    (:164-188 -- the RUNNING sum over hidden units at layer 0, a sigmoid after every layer), run by the reference's own
+    statements, against the oracle and the host code that feeds the kernels."""
+    from oracle import dae_oracle as do
+    from deep_ctr_amd import sampling_based_denosing_autoencoder as da
+    lines = [str(v) for v in ref['dae_lines']]
+    parsed = []
+    for ln in lines:
+        s = ln.strip().replace(':', ' ').split(' ')
+        parsed.append(([int(s[f]) for f in range(1, len(s), 2)], [int(s[f + 1]) for f in range(1, len(s), 2)]))
+    rs = np.random.RandomState(int(ref['dae_seed']))
+    for n, (ids, vals) in enumerate(parsed):
+        x, idx = do.sample_negatives(rs, ids, vals)
+        assert idx == unpad(ref['dae_samp_idx'][n]) and x == [int(v) for v in ref['dae_samp_x'][n][:len(x)]]
+    assert rs.random_sample() == float(ref['dae_next_draw'])                     # the stream stands where the reference's does
+    rs = np.random.RandomState(int(ref['dae_seed']))
+    idx, x = da.sampled_visibles(rs, parsed, 32)
+    assert np.array_equal(idx, ref['dae_samp_idx']) and np.array_equal(x, ref['dae_samp_x']) and rs.random_sample() == float(ref['dae_next_draw'])
+    results = [ref['dae_prop_res%d' % i] for i in range(4)]
+    for n, row in enumerate(ref['dae_prop_ids']):
+        np.testing.assert_allclose(do.propagate(results, unpad(row)), ref['dae_prop_out'][n], rtol=0, atol=1e-14)
