@@ -956,7 +956,7 @@ def bench_ipnn(args):
         for i in range(min(args.steps, 50)):
             step(i)
         eng.sync()
-        for name in ('sort', 'ip_fwd', 'fwd', 'bwd', 'wgrad', 'ip_bwd', 'scatter', 'adam_table', 'update'):
+        for name in ('sort', 'mask_t', 'ip_fwd', 'fwd', 'bwd', 'wgrad', 'ip_bwd', 'scatter', 'adam_table', 'update'):
             ms = C.c_double()
             lib.ipnn_prof_get(h, name.encode(), C.byref(ms))
             seg[name] = ms.value

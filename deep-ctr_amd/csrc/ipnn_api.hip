@@ -100,9 +100,9 @@ __device__ __forceinline__ void ip_gather16(float* se, const int32_t* __restrict
     }
 }
 
-constexpr int IPF_NT = 512;     // 8 waves: the kernel is bound by instruction issue, two waves per SIMD overlap it
-template <typename T>
-static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T, float* __restrict__ emb)
+constexpr int IPF_NT = 512;     // 8 waves: the kernel is bound by instruction issue, two waves per SIMD overlap it (IPNN_IPF_NT=1024: four)
+template <typename T, int NT = IPF_NT>
+static __global__ __launch_bounds__(NT) void k_ip_fwd(const IpFwdArgs a, T* __restrict__ a0, T* __restrict__ a0T, float* __restrict__ emb)
 {
     typedef typename Traits<T>::frag frag;
     constexpr int EPL = Traits<T>::EPL;
@@ -112,17 +112,18 @@ static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* 
     float* sa = se + 16 * a.F * SP;                             // [16][D0p]  a0 values
     const int tid = threadIdx.x, t0 = blockIdx.x * 16, F = a.F, K = a.K, B = a.B, FS = F * SLOT, FSP = F * SP;
     const int P = a.P, CB = FS + P;
-    if (!(a.skip & 1)) ip_gather16<SP, IPF_NT>(se, a.ids, a.table16, a.n_rows, t0, B, F, a.err);
+    if (!(a.skip & 1)) ip_gather16<SP, NT>(se, a.ids, a.table16, a.n_rows, t0, B, F, a.err);
     __syncthreads();
     if (emb && !(a.skip & 2))                                                    // kept for the backward of the inner products (no second gather)
-        for (int e = tid; e < 16 * FS / 4; e += IPF_NT) {
+        for (int e = tid; e < 16 * FS / 4; e += NT) {
             const int r = (4 * e) / FS, c = (4 * e) % FS;
             const float* q = se + r * FSP + (c >> 4) * SP + (c & 15);
             *reinterpret_cast<float4*>(emb + (size_t)t0 * FS + 4 * e) = make_float4(q[0], q[1], q[2], q[3]);
         }
     const float bval = *a.b;
-    // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + 8 i; 8 columns at a time: their pair indices,
-    // then all 32 keep-mask bytes (one round trip), then the values
+    // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + NWV i; 8 columns at a time: their pair indices,
+    // then all 8 RPT keep-mask bytes (one round trip), then the values
+    constexpr int NWV = NT / 64, RPT = 16 / NWV;
     for (int c0 = tid & 63; c0 < ((a.skip & 4) ? 0 : a.D0p); c0 += 512) {
         int ref[8], pi[8], pj[8];                               // ref: column in the reference's z1 order
 #pragma unroll
@@ -136,12 +137,12 @@ static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* 
                 pi[k] = i; pj[k] = i + 1 + n; ref[k] = F * K + (c - FS);
             } else if (c == CB) ref[k] = a.d0 - 1;
         }
-        float mk[8][2];
+        float mk[8][RPT];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int t = t0 + (tid >> 6) + 8 * i;
+            for (int i = 0; i < RPT; ++i) {
+                const int t = t0 + (tid >> 6) + NWV * i;
                 mk[k][i] = (a.mask && ref[k] >= 0 && t < B) ? (float)a.mask[(size_t)t * a.d0 + ref[k]] * a.inv_keep : 1.0f;
             }
 #pragma unroll
@@ -149,8 +150,8 @@ static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* 
             const int c = c0 + 64 * k;
             if (c >= a.D0p) break;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = (tid >> 6) + 8 * i, t = t0 + r;
+            for (int i = 0; i < RPT; ++i) {
+                const int r = (tid >> 6) + NWV * i, t = t0 + r;
                 float z = 0.f;
                 if (c < FS) z = se[r * FSP + (c >> 4) * SP + (c & 15)];
                 else if (c < CB) {
@@ -170,14 +171,14 @@ static __global__ __launch_bounds__(IPF_NT) void k_ip_fwd(const IpFwdArgs a, T* 
     __syncthreads();
     // F layout: this workgroup's 16 rows are one row tile; a lane-slot of a fragment = EPL consecutive columns of one row
     if (a.skip & 8) return;
-    for (int e = tid; e < 16 * a.D0p / EPL; e += IPF_NT) {
+    for (int e = tid; e < 16 * a.D0p / EPL; e += NT) {
         const int g = e >> 4, r = e & 15;                        // column group, row
         frag fv;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) fv[x] = (T)sa[r * a.D0p + g * EPL + x];
         *reinterpret_cast<frag*>(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p)) = fv;
     }
-    for (int e = tid; e < a.D0p * 4; e += IPF_NT) {
+    for (int e = tid; e < a.D0p * 4; e += NT) {
         const int c = e >> 2, tq = e & 3;
         store4(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
                sa[(4 * tq + 2) * a.D0p + c], sa[(4 * tq + 3) * a.D0p + c]);
@@ -381,6 +382,7 @@ template <typename T> struct StripFwdArgs {
     // (element offset there, or -1: streamed from L2 as usual).  The narrow products are chains of a few k-steps, each an L2 round
     // trip long (~600 ticks with four in flight); from LDS a k-step costs what its MFMAs cost
     int wlds[STRIP_MAXP];
+    int warm;                                                    // touch every line of these arguments at the start (see strip_warm_args)
 };
 template <typename T> struct StripBwdArgs {
     const T* dlast; int n;                                       // delta of the output layer, F layout [Ba][64]
@@ -393,40 +395,56 @@ template <typename T> struct StripBwdArgs {
     // the stack and product 1's tile leaves for HBM in the F layout (finalF: the next launch's dlast)
     int bottom; T* finalF;
     int wlds[STRIP_MAXP];                                        // as in StripFwdArgs (index = product index t - 1 of this launch)
+    int warm;
 };
+// The kernels read their per-product arguments (ef[l] / eb[t - 1]: a different 64-byte line of the argument segment per product) with
+// scalar loads at the top of each product, behind the barrier: a scalar-cache miss on every wave's critical path, once per product.
+// One dword of every line at the start of the launch instead -- all misses in flight together, under the strip's own load.
+template <int BYTES> __device__ __forceinline__ void strip_warm_args()
+{
+    typedef const int __attribute__((address_space(4))) karg_int;
+    karg_int* p = (karg_int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int s = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) s |= p[o / 4];
+    asm volatile("" :: "s"(s));
+}
 
 // one 64-column block of one product: acc[m][n] = sum_k in[16 m ..][k] W[64 blk + 16 n ..][k].
 // Weights: five register stages (four k-steps in flight while one multiplies: with two waves per SIMD that
 // covers an L2 round trip at the rate the texture path delivers fragments); loads past the end are clamped
 // to the last k-step, so the loop has no branch.  The strip's own fragments come from LDS.
-template <typename T> struct StripB { typename Traits<T>::frag s[4][4]; };     // k-steps 0..3 of a block's weights, in flight
+// An ITEM of a product is NF of its 16-column fragments: NF = 4 (a 64-column block) everywhere but in the 16-example strips of
+// the narrow tail, whose kernels may take finer items (k_ip_strip_*<T, 1, NF>): a 64- or 128-wide product then occupies 4 / 8
+// waves instead of 1 / 2, and an item's epilogue is NF / 4 of a block's.  `blk` below is the item index: fragments blk NF + n.
+template <typename T, int NF = 4> struct StripB { typename Traits<T>::frag s[4][NF]; };     // k-steps 0..3 of an item's weights, in flight
 
-template <typename T>
-__device__ __forceinline__ void strip_prefetch(StripB<T>& pb, const T* __restrict__ W, const int nkt, const int blk, const int lane)
+template <typename T, int NF = 4>
+__device__ __forceinline__ void strip_prefetch(StripB<T, NF>& pb, const T* __restrict__ W, const int nkt, const int blk, const int lane)
 {
     typedef typename Traits<T>::frag frag;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) pb.s[j][n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * 4 + n, min(j, nkt - 1), nkt, lane));
+        for (int n = 0; n < NF; ++n) pb.s[j][n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * NF + n, min(j, nkt - 1), nkt, lane));
 }
 
-template <typename T, int RT>
-__device__ __forceinline__ void strip_product(f32x4 (&acc)[RT][4], StripB<T>& pb, const T* in, const T* __restrict__ W, const int nkt,
+template <typename T, int RT, int NF = 4>
+__device__ __forceinline__ void strip_product(f32x4 (&acc)[RT][NF], StripB<T, NF>& pb, const T* in, const T* __restrict__ W, const int nkt,
                                               const int blk, const int lane)
 {
     typedef typename Traits<T>::frag frag;
 #pragma unroll
     for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    frag b4[4];
-    frag (&b0)[4] = pb.s[0]; frag (&b1)[4] = pb.s[1]; frag (&b2)[4] = pb.s[2]; frag (&b3)[4] = pb.s[3];
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag b4[NF];
+    frag (&b0)[NF] = pb.s[0]; frag (&b1)[NF] = pb.s[1]; frag (&b2)[NF] = pb.s[2]; frag (&b3)[NF] = pb.s[3];
     const int last = nkt - 1;
     auto loadb = [&](frag* b, const int kt) {
         const int k = min(kt, last);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * 4 + n, k, nkt, lane));
+        for (int n = 0; n < NF; ++n) b[n] = *reinterpret_cast<const frag*>(ft_frag<T>(W, blk * NF + n, k, nkt, lane));
     };
     auto mul = [&](const int kt, const frag* b) {
         frag a[RT];
@@ -435,7 +453,7 @@ __device__ __forceinline__ void strip_product(f32x4 (&acc)[RT][4], StripB<T>& pb
 #pragma unroll
         for (int m = 0; m < RT; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) mma(acc[m][n], a[m], b[n]);
+            for (int n = 0; n < NF; ++n) mma(acc[m][n], a[m], b[n]);
     };
     int kt = 0;
     for (; kt + 5 <= nkt; kt += 5) {
@@ -456,32 +474,33 @@ __device__ __forceinline__ void strip_product(f32x4 (&acc)[RT][4], StripB<T>& pb
 }
 
 // what the epilogue of a block reads from memory (keep-mask bytes, activations for act'), fetched before the k-loop
-template <typename T, int RT, typename Epi>
-__device__ __forceinline__ void strip_aux(typename Epi::Aux (&ax)[RT][4], const Epi& epi, const int row0, const int blk, const int lane)
+template <typename T, int RT, int NF, typename Epi>
+__device__ __forceinline__ void strip_aux(typename Epi::Aux (&ax)[RT][NF], const Epi& epi, const int row0, const int blk, const int lane)
 {
     const int rq = 4 * (lane >> 4), cl = lane & 15;
 #pragma unroll
     for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) ax[m][n] = epi.load(row0 + m * 16 + rq, blk * 64 + n * 16 + cl);
+        for (int n = 0; n < NF; ++n) ax[m][n] = epi.load(row0 + m * 16 + rq, (blk * NF + n) * 16 + cl);
 }
 
 // epilogue of a block: the lane's values through `epi.apply`, the transposed layout to HBM (8-byte pieces),
 // the strip's own layout to the LDS tile `out` (the next product's A operand) when there is a next product
-template <int ACT, bool PLAIN, typename T, int RT, typename Epi>
-__device__ __forceinline__ void strip_epilogue_a(f32x4 (&acc)[RT][4], const typename Epi::Aux (&ax)[RT][4], const Epi& epi, T* out, const int N,
+template <int ACT, bool PLAIN, typename T, int RT, int NF, typename Epi>
+__device__ __forceinline__ void strip_epilogue_a(f32x4 (&acc)[RT][NF], const typename Epi::Aux (&ax)[RT][NF], const Epi& epi, T* out, const int N,
                                                  const int row0, const int blk, const int lane)
 {
-    const int rq = 4 * (lane >> 4), cl = lane & 15;
-    T* const outT = epi.outT ? epi.outT + ft_off<T>(blk * 64 + cl, row0 + rq, epi.ldT) : nullptr;   // + n * 16 units, + m * 16 examples
-    T* const outL = out ? out + ft_off<T>(rq, blk * 64 + cl, N) : nullptr;
+    const int rq = 4 * (lane >> 4), cl = lane & 15, col0 = blk * NF * 16;
+    T* const outT = epi.outT ? epi.outT + ft_off<T>(col0 + cl, row0 + rq, epi.ldT) : nullptr;   // + n * 16 units, + m * 16 examples
+    // (the item's first column is a multiple of 16 NF: with NF < 4 offsets of n * 16 columns still add without a carry into the k-step)
+    T* const outL = out ? out + ft_off<T>(rq, col0 + cl, N) : nullptr;
     const size_t tn = ft_off<T>(16, 0, epi.ldT), tm = ft_off<T>(0, 16, epi.ldT);    // strides: 16 units, 16 examples (ldT % KS == 0)
 #pragma unroll
     for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NF; ++n) {
             float v[4];
-            const int col = blk * 64 + n * 16 + cl;
+            const int col = col0 + n * 16 + cl;
             epi.template applyA<ACT, PLAIN>(ax[m][n], row0 + m * 16 + rq, col, acc[m][n], v);
             if (outT) store4(outT + n * tn + m * tm, v[0], v[1], v[2], v[3]);
             if (outL) {
@@ -491,13 +510,13 @@ __device__ __forceinline__ void strip_epilogue_a(f32x4 (&acc)[RT][4], const type
             }
         }
 }
-template <typename T, int RT, typename Epi>
-__device__ __forceinline__ void strip_epilogue(f32x4 (&acc)[RT][4], const typename Epi::Aux (&ax)[RT][4], const Epi& epi, T* out, const int N,
+template <typename T, int RT, int NF, typename Epi>
+__device__ __forceinline__ void strip_epilogue(f32x4 (&acc)[RT][NF], const typename Epi::Aux (&ax)[RT][NF], const Epi& epi, T* out, const int N,
                                                const int row0, const int blk, const int lane)
 {   // one branch on the activation and on "interior block" per block
-    const bool pl = epi.plain(row0 + RT * 16, blk * 64 + 64);
-#define STRIP_EPI(ACT) do { if (pl) strip_epilogue_a<ACT, true, T, RT, Epi>(acc, ax, epi, out, N, row0, blk, lane); \
-                            else strip_epilogue_a<ACT, false, T, RT, Epi>(acc, ax, epi, out, N, row0, blk, lane); } while (0)
+    const bool pl = epi.plain(row0 + RT * 16, (blk + 1) * NF * 16);
+#define STRIP_EPI(ACT) do { if (pl) strip_epilogue_a<ACT, true, T, RT, NF, Epi>(acc, ax, epi, out, N, row0, blk, lane); \
+                            else strip_epilogue_a<ACT, false, T, RT, NF, Epi>(acc, ax, epi, out, N, row0, blk, lane); } while (0)
     if (epi.act == A_RELU) STRIP_EPI(A_RELU);
     else if (epi.act == A_TANH) STRIP_EPI(A_TANH);
     else STRIP_EPI(A_SIG);
@@ -533,13 +552,23 @@ __device__ __forceinline__ int strip_phys(const bool split, const int i, const i
     const int r = (i + rot) % cnt;
     return split ? 2 * r + h : r;
 }
-template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd, const int h)
+template <typename T> __device__ __forceinline__ bool strip_has_out(const StripFwdArgs<T>& a) { return a.has_out != 0; }
+template <typename T> __device__ __forceinline__ bool strip_has_out(const StripBwdArgs<T>&) { return false; }
+// items of a product in a workgroup's list: `per` items per 64-column block (4 / NF; pairs split whole blocks: per = 1 there);
+// the output unit is ONE item whatever its padded width (column 0 is the only unit)
+template <typename A> __device__ __forceinline__ int strip_items(const A& a, const int p, const bool fwd, const int h, const int per)
+{
+    const int nblk = fwd ? a.Dp[p + 1] / 64 : a.Dp[a.n - p - 1] / 64;
+    if (fwd && strip_has_out(a) && p == a.n - 1) return 1;
+    return duo_count(duo_split(a.duo, nblk), nblk, h) * per;
+}
+template <typename A> __device__ __forceinline__ StripItem strip_next(const A& a, StripItem it, const int wave, const bool fwd, const int h, const int per,
+                                                                     const int nw = STRIP_NW)
 {   // fwd: product p has Dp[p + 1] / 64 blocks (the output unit, p = n - 1: one); bwd: product index q = n - t, Dp[t - 1] / 64 blocks
-    it.blk += STRIP_NW;
+    it.blk += nw;
     for (;;) {
         if (it.p >= a.n) return it;
-        const int nblk = fwd ? a.Dp[it.p + 1] / 64 : a.Dp[a.n - it.p - 1] / 64;
-        if (it.blk < duo_count(duo_split(a.duo, nblk), nblk, h)) return it;
+        if (it.blk < strip_items(a, it.p, fwd, h, per)) return it;
         it.p += 1; it.blk = wave;
     }
 }
@@ -567,17 +596,23 @@ __device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const 
 }
 // block j of the tile `out`, just written by this wave, to its place in an F-layout operand in HBM (plain 16-byte stores; the
 // strip's row tiles are contiguous there, so the tile's own offsets apply): the hand-over between two launches of a split stack
-template <typename T, int RT>
+template <typename T, int RT, int NF = 4>
 __device__ __forceinline__ void strip_final_push(T* __restrict__ dstF, const T* out, const int N, const int sidx, const int j, const int lane)
-{
+{   // item j = columns 16 NF j ..: per row tile 16 x 16 NF elements, contiguous in the fragment-tiled layout (NF = 1, bf16: half a fragment)
+    constexpr int PIECES = 16 * NF * (int)sizeof(T);             // 16-byte pieces per row tile
     T* base = dstF + (size_t)sidx * RT * 16 * N;
 #pragma unroll
     for (int m = 0; m < RT; ++m) {
-        const size_t o = ft_off<T>(m * 16, j * 64, N);
+        const size_t o = ft_off<T>(m * 16, j * NF * 16, N);
         const duo_u32x4* src = reinterpret_cast<const duo_u32x4*>(out + o);
         duo_u32x4* dst = reinterpret_cast<duo_u32x4*>(base + o);
-        const duo_u32x4 v0 = src[lane], v1 = src[lane + 64];
-        dst[lane] = v0; dst[lane + 64] = v1;
+        if (PIECES >= 128) {
+            duo_u32x4 v[PIECES / 64 > 0 ? PIECES / 64 : 1];
+#pragma unroll
+            for (int i = 0; i < PIECES / 64; ++i) v[i] = src[lane + 64 * i];
+#pragma unroll
+            for (int i = 0; i < PIECES / 64; ++i) dst[lane + 64 * i] = v[i];
+        } else if (lane < PIECES) dst[lane] = src[lane];
     }
 }
 // every wave has drained its pushes -> flag -> the partner's flag -> the partner's blocks into `out`.  `pull` = false: this
@@ -625,10 +660,10 @@ __device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N,
     if (dbg && threadIdx.x == 0) dbg[13] += (long long)__builtin_amdgcn_s_memtime() - ta;                  // pull (thread 0's share)
 }
 
-template <typename T, int RT>
-static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const StripFwdArgs<T> a, const int maxD)
+template <typename T, int RT, int NF = 4, int NW = STRIP_NW>
+static __global__ __launch_bounds__(64 * NW) void k_ip_strip_fwd(const StripFwdArgs<T> a, const int maxD)
 {
-    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, PER = 4 / NF;       // NF < 4: no pairs (the host launches those without StripDuo)
     extern __shared__ __align__(16) unsigned char strip_smem[];
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
@@ -637,21 +672,22 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     const int h = a.duo.on ? (int)(blockIdx.x & 1) : 0, sidx = a.duo.on ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     const int row0 = sidx * RT * 16;
     STRIP_STAMP(0);
+    if (a.warm) strip_warm_args<(int)sizeof(StripFwdArgs<T>)>();
     if (a.dbg && threadIdx.x == 0) { for (int i = 10; i < 16; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = 0; }
-    StripB<T> pb;
-    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, true, h);
+    StripB<T, NF> pb;
+    StripItem nx = strip_next(a, StripItem{0, wave - NW}, wave, true, h, PER, NW);
     const int rot = (a.rot == 1) ? (sidx >> 3) : (a.rot == 2 ? sidx : 0);   // workgroups g, g + 8, ... share an XCD
     // the last product this workgroup computes: the second of a pair stops behind the last product the pair splits
     int last = a.n - 1;
     if (h == 1) { last = -1; for (int p = 0; p < a.n; ++p) if (duo_split(a.duo, a.Dp[p + 1] / 64)) last = p; }
-    auto blocks = [&](const int p, bool& split, int& cnt) { const int nb = a.Dp[p + 1] / 64; split = duo_split(a.duo, nb); cnt = duo_count(split, nb, h); };
+    auto blocks = [&](const int p, bool& split, int& cnt) { split = duo_split(a.duo, a.Dp[p + 1] / 64); cnt = strip_items(a, p, true, h, PER); };
     auto prefetch_next = [&]() {
         if (nx.p < a.n && nx.p <= last) {
             bool sp; int cn; blocks(nx.p, sp, cn);
             const int wo = RT == 1 ? a.wlds[nx.p] : -1;
             // (spelled from the LDS array itself: through the captured pointer the address space was lost and the loads came out flat_)
-            if (wo >= 0) strip_prefetch<T>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
-            else strip_prefetch<T>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            else strip_prefetch<T, NF>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
         }
     };
     if (RT == 1) {                                               // the small products' weights -> LDS (contiguous, fragment-tiled: offsets carry over)
@@ -667,7 +703,7 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
     strip_load<T>(in, a.a0 + (size_t)sidx * RT * 16 * a.Dp[0], RT * 16 * a.Dp[0] / EPL);
     lds_barrier();
     STRIP_STAMP(1);
-    f32x4 acc[RT][4];
+    f32x4 acc[RT][NF];
     int seq = 0;
     for (int l = 0; l <= last; ++l) {
         const int nkt = a.Dp[l] / KS, N = a.Dp[l + 1];
@@ -682,21 +718,21 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
             if (hidden) {
                 EpiIpFwd<T> ef = a.ef[l];                       // the layer's epilogue parameters: scalar registers, loaded once
                 if (a.duo.on && !split && h == 1) ef.outT = nullptr;     // (not reached: the second workgroup computes split products only)
-                typename EpiIpFwd<T>::Aux ax[RT][4];
-                strip_aux<T, RT>(ax, ef, row0, blk, lane);
-                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
-                else strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                typename EpiIpFwd<T>::Aux ax[RT][NF];
+                strip_aux<T, RT, NF>(ax, ef, row0, blk, lane);
+                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT, NF>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
+                else strip_product<T, RT, NF>(acc, pb, in, a.W[l], nkt, blk, lane);
                 DET(11);
-                nx = strip_next(a, nx, wave, true, h);
+                nx = strip_next(a, nx, wave, true, h, PER, NW);
                 prefetch_next();
                 DET(12);
-                strip_epilogue<T, RT>(acc, ax, ef, out, N, row0, blk, lane);
+                strip_epilogue<T, RT, NF>(acc, ax, ef, out, N, row0, blk, lane);
                 DET(13);
-                if (fin) { if (split || h == 0) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane); }
-                else if (split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
-            } else {                                              // the output unit: logits, loss, delta (column 0)
-                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
-                else strip_product<T, RT>(acc, pb, in, a.W[l], nkt, blk, lane);
+                if (fin) { if (split || h == 0) strip_final_push<T, RT, NF>(a.finalF, out, N, sidx, blk, lane); }
+                else if (NF == 4 && split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+            } else {                                              // the output unit: logits, loss, delta (column 0): item 0 = fragment 0 ..
+                if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT, NF>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
+                else strip_product<T, RT, NF>(acc, pb, in, a.W[l], nkt, blk, lane);
                 nx.p = a.n;
                 const EpiIpOut<T> eo = a.eo;
                 const int rq = 4 * (lane >> 4), cl = lane & 15;
@@ -715,17 +751,17 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_fwd(const Str
                 }
             }
         }
-        if (split && !fin) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
+        if (NF == 4 && split && !fin) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (hidden && !fin) lds_barrier();
         STRIP_STAMP(2 + l);
         T* t = in; in = out; out = t;
     }
 }
 
-template <typename T, int RT>
-static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const StripBwdArgs<T> a, const int maxD)
+template <typename T, int RT, int NF = 4, int NW = STRIP_NW>
+static __global__ __launch_bounds__(64 * NW) void k_ip_strip_bwd(const StripBwdArgs<T> a, const int maxD)
 {
-    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
+    constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, PER = 4 / NF;
     extern __shared__ __align__(16) unsigned char strip_smem[];
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
@@ -733,18 +769,19 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     const int h = a.duo.on ? (int)(blockIdx.x & 1) : 0, sidx = a.duo.on ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     const int row0 = sidx * RT * 16;
     STRIP_STAMP(0);
+    if (a.warm) strip_warm_args<(int)sizeof(StripBwdArgs<T>)>();
     if (a.dbg && threadIdx.x == 0) { for (int i = 10; i < 16; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = 0; }
     T* wl = out + (size_t)RT * 16 * maxD;                        // RT = 1: LDS copies of the small products' weights (a.wlds)
-    StripB<T> pb;                                                 // item index q = n - t: product t = n - q
-    StripItem nx = strip_next(a, StripItem{0, wave - STRIP_NW}, wave, false, h);
+    StripB<T, NF> pb;                                             // item index q = n - t: product t = n - q
+    StripItem nx = strip_next(a, StripItem{0, wave - NW}, wave, false, h, PER, NW);
     const int rot = (a.rot == 1) ? (sidx >> 3) : (a.rot == 2 ? sidx : 0);   // workgroups g, g + 8, ... share an XCD
-    auto blocks = [&](const int q, bool& split, int& cnt) { const int nb = a.Dp[a.n - q - 1] / 64; split = duo_split(a.duo, nb); cnt = duo_count(split, nb, h); };
+    auto blocks = [&](const int q, bool& split, int& cnt) { split = duo_split(a.duo, a.Dp[a.n - q - 1] / 64); cnt = strip_items(a, q, false, h, PER); };
     auto prefetch_next = [&]() {
         if (nx.p < a.n) {
             bool sp; int cn; blocks(nx.p, sp, cn);
             const int wo = RT == 1 ? a.wlds[a.n - nx.p - 1] : -1;
-            if (wo >= 0) strip_prefetch<T>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
-            else strip_prefetch<T>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            else strip_prefetch<T, NF>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
         }
     };
     if (RT == 1) {                                               // the small products' weights -> LDS; in the backward launch they are the FIRST products
@@ -757,7 +794,7 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
     strip_load<T>(in, a.dlast + (size_t)sidx * RT * 16 * a.Dp[a.n], RT * 16 * a.Dp[a.n] / EPL);
     lds_barrier();
     STRIP_STAMP(1);
-    f32x4 acc[RT][4];
+    f32x4 acc[RT][NF];
     int seq = 0;
     for (int t = a.n; t >= 1; --t) {                              // delta l_{t-1} = (delta l_t . W_t^T) * mask * act'
         const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
@@ -766,17 +803,17 @@ static __global__ __launch_bounds__(64 * STRIP_NW) void k_ip_strip_bwd(const Str
             const int blk = strip_phys(split, nx.blk, cnt, h, rot);
             EpiIpBwd<T> eb = a.eb[t - 1];
             if (a.duo.on && !split && h == 1) { eb.outT = nullptr; eb.out32 = nullptr; }   // a narrow product of a pair: both compute it, the first one stores it
-            typename EpiIpBwd<T>::Aux ax[RT][4];
-            strip_aux<T, RT>(ax, eb, row0, blk, lane);
-            if (RT == 1 && a.wlds[t - 1] >= 0) strip_product<T, RT>(acc, pb, in, wl + a.wlds[t - 1], nkt, blk, lane);
-            else strip_product<T, RT>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
-            nx = strip_next(a, nx, wave, false, h);
+            typename EpiIpBwd<T>::Aux ax[RT][NF];
+            strip_aux<T, RT, NF>(ax, eb, row0, blk, lane);
+            if (RT == 1 && a.wlds[t - 1] >= 0) strip_product<T, RT, NF>(acc, pb, in, wl + a.wlds[t - 1], nkt, blk, lane);
+            else strip_product<T, RT, NF>(acc, pb, in, a.W[t - 1], nkt, blk, lane);
+            nx = strip_next(a, nx, wave, false, h, PER, NW);
             prefetch_next();
-            strip_epilogue<T, RT>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
-            if (split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
-            if (t == 1 && !a.bottom && (split || h == 0)) strip_final_push<T, RT>(a.finalF, out, N, sidx, blk, lane);
+            strip_epilogue<T, RT, NF>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
+            if (NF == 4 && split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+            if (t == 1 && !a.bottom && (split || h == 0)) strip_final_push<T, RT, NF>(a.finalF, out, N, sidx, blk, lane);
         }
-        if (split && t > 1) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
+        if (NF == 4 && split && t > 1) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (t > 1) lds_barrier();
         STRIP_STAMP(2 + q);
         T* x = in; in = out; out = x;
@@ -799,6 +836,7 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     const int t0 = (local % ntx) * 64, c0 = (local / ntx) * 64;
     {   // a thread's column is the same in all 16 of its elements (i = tid + 256 k): its source column once, then all
         // 16 bytes in one round trip, then the LDS transposition
+        // (four such tiles per workgroup, 64 loads in flight per thread, changed nothing: 12.0 against 12.2 us -- not a latency chain)
         const int cx = threadIdx.x & 63, c = c0 + cx, d = a.d[t];
         int sc = c < a.Dp[t] ? c : -1;
         if (t == 0) sc = sc >= 0 ? a.ref0[sc] : -1; else if (sc >= d) sc = -1;
@@ -1009,6 +1047,12 @@ struct ipnn_handle {
     std::vector<void*> a, aT, dl, dlT;                           // a[t] t=0..L ; dl[t] t=1..L+1 (index t-1)
     std::vector<uint8_t*> maskT;                                 // keep-masks of a step, transposed [Dp_t][ldT], t = 0..L
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mask = nullptr, ev_bwd = nullptr;
+    // IPNN_UPDATE_SIDE=1 (default 0, measured slower -- DESIGN.md section 4): the dense update runs at the END of the side chain (behind ev_wg: the weight gradients) and the main
+    // stream does NOT wait for it at the end of the step: the next call's mask transposition and gather -- which read neither the dense
+    // weights nor the slabs -- run beside it, and the wait (ev_join) sits in front of the first product.  ev_tab: the side chain's table /
+    // bias half is done (in front of the next gather).  Every other entry point joins first (ip_join).
+    hipEvent_t ev_tab = nullptr, ev_wg = nullptr;
+    bool upd_side = false, tab_pending = false, upd_pending = false;
     // side stream (IPNN_SIDE_STREAM=0: everything in line): the id grouping from the start of the step; the inner-product backward,
     // the scalar b and the sparse-row update beside the weight gradients.  ev_fork / ev_bwd: main -> side; ev_join: side -> main at
     // the end of the step (ev_mask only with IPNN_MASK_SIDE=1)
@@ -1025,6 +1069,10 @@ struct ipnn_handle {
     int mask_side = 0;                               // IPNN_MASK_SIDE=1: the mask transposition on the side stream
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
+    int tail_nf = 1;                                 // IPNN_TAIL_NF: 16-column fragments per item in the 16-example strips of the narrow tail (1 / 2 / 4)
+    int tail_nw = 16;                                // IPNN_TAIL_NW: waves per workgroup there (16 with IPNN_TAIL_NF=1 only: 128 registers per lane)
+    int ipf_nt = 1024;                               // IPNN_IPF_NT: threads per workgroup of the gather + inner-product launch (512 / 1024)
+    int strip_warm = 1;                              // IPNN_STRIP_WARM: the strip kernels touch their argument lines at the start (strip_warm_args)
     bool strip = true;                               // IPNN_STRIP=0: one GEMM launch per product instead of the strip kernels
     int duo = 1, duo_min = DUO_MIN_BLOCKS;           // IPNN_STRIP_DUO=0: one workgroup per strip (StripDuo); IPNN_DUO_MIN: narrowest product a pair splits
     unsigned long long* duo_xch = nullptr; int* duo_flags = nullptr; int duo_epoch = 0; size_t duo_xch_wg = 0; int n_cu = 256;
@@ -1062,6 +1110,20 @@ template <typename T> void ip_refresh(ipnn_handle* h, int t, const float* slab, 
 
 inline int maxD2x(const int* Dp, int n) { int m = 0; for (int t = 0; t <= n; ++t) m = std::max(m, Dp[t]); return m; }
 
+// the main stream waits for what the previous step left running on the side stream (see upd_side)
+static int ip_join_table(ipnn_handle* h)
+{
+    if (h->tab_pending) { IHK(h, hipStreamWaitEvent(h->st, h->ev_tab, 0)); h->tab_pending = false; }
+    return FNN_OK;
+}
+static int ip_join(ipnn_handle* h)
+{
+    const int rc = ip_join_table(h);
+    if (rc != FNN_OK) return rc;
+    if (h->upd_pending) { IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0)); h->upd_pending = false; }
+    return FNN_OK;
+}
+
 template <typename T>
 int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint8_t* const* masks, float* logits_out,
            float* p_out, bool train)
@@ -1071,6 +1133,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     const size_t lds_ip = (size_t)16 * (F * (SLOT + 1) + h->Dp[0]) * sizeof(float);    // k_ip_fwd pads its embedding tile
     const bool drop = train && masks;
     if (drop) for (int t = 0; t <= L; ++t) if (!masks[t]) IFAIL(h, FNN_ERR_ARG, "masks: null entry");
+    { const int jrc = ip_join_table(h); if (jrc != FNN_OK) return jrc; }      // the previous step's sparse rows / bias (read by the gather)
     if (train) {
         // beside the stack, on the side stream: the grouping of the batch's ids for the sparse-row update (needed by the scatter);
         // the transposed keep-masks (needed from the first product on) go first on the main stream
@@ -1089,6 +1152,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             // transposing the NEXT step's masks ahead, on the side stream -- beside the strips: 0.265 -> 0.270 ms per step, at the end
             // of the side chain beside the weight gradients: 0.286 -> 0.302 on a slower box: every kernel of this step is bound by
             // the CUs' ports or the L2, and a co-running launch takes what it saves.  Not kept.)
+            IpProf pm(h, "mask_t", h->mask_side ? ss : h->st);
             hipLaunchKernelGGL(k_mask_T, dim3(tiles), dim3(256), 0, h->mask_side ? ss : h->st, ma);
             if (h->st2 && h->mask_side) IHK(h, hipEventRecord(h->ev_mask, h->st2));
         }
@@ -1105,7 +1169,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
                      (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag, h->fwd_skip};
-        hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(IPF_NT), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
+        if (h->ipf_nt == 1024) hipLaunchKernelGGL((k_ip_fwd<T, 1024>), dim3(Ba / 16), dim3(1024), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
+        else hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(IPF_NT), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
     }
     // one product: C [M][N] = A . B^T on fragment-tiled operands; narrow problems take smaller wave tiles
     auto gemm = [&](const T* A, const T* Bm, int M, int N, int nkt_all, int nkt, int splitk, auto epi) {
@@ -1130,6 +1195,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                mt16, nt16, nkt_all, nkt, epi);
     };
     if (drop && h->st2 && h->mask_side) IHK(h, hipStreamWaitEvent(h->st, h->ev_mask, 0));     // the strips / GEMMs read the transposed masks
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }            // the previous step's dense update (read from here on)
     constexpr int KS = Traits<T>::KS;
     int maxD = 0;
     for (int t = 0; t <= L + 1; ++t) maxD = std::max(maxD, h->Dp[t]);
@@ -1158,6 +1224,12 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->strip_attr = true;
         }
     }
@@ -1200,7 +1272,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         sa.eo = EpiIpOut<T>{train ? (T*)h->dl[L] : nullptr, h->Dp[L + 1], train ? (T*)h->dlT[L] : nullptr, ldT, train ? y : nullptr,
                             logits_out, h->loss_t, p_out, B, h->loss_mean ? 1.0f / (float)B : 1.0f};
         sa.dbg = h->stamps; sa.rot = h->strip_rot; sa.sel = getenv("IPNN_STAMP_SEL") ? atoi(getenv("IPNN_STAMP_SEL")) : -1;
-        sa.has_out = 1; sa.finalF = nullptr;
+        sa.has_out = 1; sa.finalF = nullptr; sa.warm = h->strip_warm;
         for (int t = 0; t < STRIP_MAXP; ++t) sa.wlds[t] = -1;
         if (!tsplit) {
             sa.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
@@ -1214,12 +1286,15 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             for (int t = cut; t <= L + 1; ++t) s2.Dp[t - cut] = h->Dp[t];
             for (int t = cut + 1; t <= L + 1; ++t) s2.W[t - cut - 1] = sa.W[t - 1];
             for (int t = cut + 1; t <= L; ++t) s2.ef[t - cut - 1] = sa.ef[t - 1];
-            s2.eo = sa.eo; s2.dbg = h->stamp_tail ? h->stamps : nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr;
+            s2.eo = sa.eo; s2.dbg = h->stamp_tail ? h->stamps : nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr; s2.warm = sa.warm;
             if (h->stamp_tail) s1.dbg = nullptr;
             s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
             hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
             const size_t wl2 = lds_weights(s2.Dp, s2.n, s2.wlds);
-            hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
+            if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wl2, h->st, s2, maxD2);
+            else if (h->tail_nf == 1) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
+            else if (h->tail_nf == 2) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 2>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
+            else hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
         }
     } else {
     IpProf ps(h, "fwd");
@@ -1248,7 +1323,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                                        first ? h->ref0 : nullptr};
         }
         sb.dbg = h->stamps ? h->stamps + (size_t)(h->ldT / 16) * 16 : nullptr; sb.rot = h->strip_rot;
-        sb.bottom = 1; sb.finalF = nullptr;
+        sb.bottom = 1; sb.finalF = nullptr; sb.warm = h->strip_warm;
         for (int t = 0; t < STRIP_MAXP; ++t) sb.wlds[t] = -1;
         if (!tsplit) {
             sb.duo = StripDuo{duo ? 1 : 0, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
@@ -1258,10 +1333,13 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             sA.dlast = (const T*)h->dl[L]; sA.n = L + 1 - cut;
             for (int t = cut; t <= L + 1; ++t) sA.Dp[t - cut] = h->Dp[t];
             for (int t = cut + 1; t <= L + 1; ++t) { sA.W[t - cut - 1] = sb.W[t - 1]; sA.eb[t - cut - 1] = sb.eb[t - 1]; }
-            sA.dbg = h->stamp_tail ? sb.dbg : nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1];
+            sA.dbg = h->stamp_tail ? sb.dbg : nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1]; sA.warm = sb.warm;
             sA.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
             const size_t wlA = lds_weights(sA.Dp, sA.n, sA.wlds);
-            hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
+            if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wlA, h->st, sA, maxD2);
+            else if (h->tail_nf == 1) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
+            else if (h->tail_nf == 2) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 2>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
+            else hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
             StripBwdArgs<T> sB = sb;                                  // products cut .. 1: pairs of 32-example strips, from delta l_cut in HBM
             sB.dlast = (const T*)h->dl[cut - 1]; sB.n = cut;
             if (h->stamp_tail) sB.dbg = nullptr;
@@ -1311,7 +1389,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             hipLaunchKernelGGL(k_adam_table, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ss, h->table16, h->tm, h->tv, h->tG, n,
                                lr_step, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, (int)h->cfg.optimizer);
         }
-        if (h->st2) IHK(h, hipEventRecord(h->ev_join, h->st2));
+        if (h->st2) IHK(h, hipEventRecord(h->st2 && h->upd_side ? h->ev_tab : h->ev_join, h->st2));
     }
     {   // all weight gradients: gW_t [Dp_{t-1}][Dp_t] = a_{t-1}^T . delta l_t, contraction over the examples,
         // split-K slabs (the split chosen per layer so that every product fills the chip)
@@ -1343,8 +1421,11 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         }
         }
     }
+    const bool side_upd = h->st2 && h->upd_side;
+    if (side_upd) { IHK(h, hipEventRecord(h->ev_wg, h->st)); IHK(h, hipStreamWaitEvent(h->st2, h->ev_wg, 0)); }
     {
-        IpProf ps(h, "update");
+        hipStream_t us = side_upd ? h->st2 : h->st;
+        IpProf ps(h, "update", us);
         size_t off = 0;
         IpUpdArgs u{};
         for (int t = 1; t <= L + 1; ++t) {
@@ -1356,9 +1437,10 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         u.adam = h->adam ? (int)h->cfg.optimizer : 0; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.bmv = h->bmv;
         if (h->adam) for (int t = 0; t <= L; ++t) { u.Wm[t] = h->Wm[t]; u.Wv[t] = h->Wv[t]; }
         u.b = h->b; u.gb_part = h->gb_part; u.ngb = Ba / 16; u.loss_t = h->loss_t; u.Ba = Ba; u.loss_sum = h->loss_dev; u.err = h->err_flag;
-        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)(off / 4096 + 1)), dim3(256), 0, h->st, u);
+        hipLaunchKernelGGL((k_ip_update_all<T>), dim3((unsigned)(off / 4096 + 1)), dim3(256), 0, us, u);
     }
-    if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
+    if (side_upd) { IHK(h, hipEventRecord(h->ev_join, h->st2)); h->tab_pending = h->upd_pending = true; }   // joined by the next call (ip_join)
+    else if (h->st2) IHK(h, hipStreamWaitEvent(h->st, h->ev_join, 0));      // the step ends when the side chain has
     IHK(h, hipGetLastError());
     return FNN_OK;
 }
@@ -1395,6 +1477,11 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_TAIL_SPLIT")) h->tail_split = atoi(e);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
     if (const char* e = getenv("IPNN_STRIP_ROT")) h->strip_rot = atoi(e);
+    if (const char* e = getenv("IPNN_STRIP_WARM")) h->strip_warm = atoi(e);
+    if (const char* e = getenv("IPNN_UPDATE_SIDE")) h->upd_side = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_IPF_NT")) h->ipf_nt = atoi(e) == 1024 ? 1024 : 512;
+    if (const char* e = getenv("IPNN_TAIL_NW")) h->tail_nw = atoi(e) == 16 ? 16 : 8;
+    if (const char* e = getenv("IPNN_TAIL_NF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->tail_nf = v; }
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
     if (const char* e = getenv("IPNN_MASK_SIDE")) h->mask_side = atoi(e);
     if (const char* e = getenv("IPNN_FWD_SKIP")) h->fwd_skip = atoi(e);
@@ -1409,6 +1496,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
         IK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         IK(hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming));
         IK(hipEventCreateWithFlags(&h->ev_bwd, hipEventDisableTiming));
+        IK(hipEventCreateWithFlags(&h->ev_tab, hipEventDisableTiming)); IK(hipEventCreateWithFlags(&h->ev_wg, hipEventDisableTiming));
     }
     h->d.resize(h->L + 2); h->Dp.resize(h->L + 2);
     h->d[0] = h->F * h->K + h->P + 1; h->Dp[0] = rup(h->CB + 2, 64);
@@ -1481,7 +1569,7 @@ int ipnn_destroy(ipnn_handle* h)
 {
     if (!h) return FNN_ERR_ARG;
     hipSetDevice(h->dev);
-    if (h->st) hipStreamSynchronize(h->st);
+    if (h->st) { ip_join(h); hipStreamSynchronize(h->st); }
     for (auto v : {&h->wf, &h->wb, &h->a, &h->aT, &h->dl, &h->dlT}) for (void* p : *v) if (p) hipFree(p);
     for (float* p : h->W) if (p) hipFree(p);
     for (uint8_t* p : h->maskT) if (p) hipFree(p);
@@ -1497,6 +1585,8 @@ int ipnn_destroy(ipnn_handle* h)
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mask) hipEventDestroy(h->ev_mask);
     if (h->ev_bwd) hipEventDestroy(h->ev_bwd);
+    if (h->ev_tab) hipEventDestroy(h->ev_tab);
+    if (h->ev_wg) hipEventDestroy(h->ev_wg);
     if (h->own_stream && h->st) hipStreamDestroy(h->st);
     delete h;
     return FNN_OK;
@@ -1506,6 +1596,7 @@ int ipnn_sync(ipnn_handle* h)
 {
     if (!h) return FNN_ERR_ARG;
     int flag = 0;
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipMemcpyAsync(&flag, h->err_flag, 4, hipMemcpyDeviceToHost, h->st));
     IHK(h, hipStreamSynchronize(h->st));
     if (flag) {
@@ -1523,6 +1614,7 @@ int ipnn_set_table(ipnn_handle* h, const float* rows, int64_t n_rows)
 {
     if (!h || !rows || n_rows < 1) return FNN_ERR_ARG;
     IHK(h, hipSetDevice(h->dev));
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipStreamSynchronize(h->st));
     if (h->table16) hipFree(h->table16);
     IHK(h, hipMalloc((void**)&h->table16, (size_t)n_rows * SLOT * 4));
@@ -1551,6 +1643,7 @@ int ipnn_get_rows(ipnn_handle* h, const int64_t* row_ids, int64_t n, float* out)
 {
     if (!h || !row_ids || !out || n < 1 || !h->table16) return FNN_ERR_ARG;
     IHK(h, hipSetDevice(h->dev));
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     int64_t* di = nullptr; float* dout = nullptr;
     IHK(h, hipMalloc((void**)&di, n * 8)); IHK(h, hipMalloc((void**)&dout, n * h->K * 4));
     IHK(h, hipMemcpy(di, row_ids, n * 8, hipMemcpyHostToDevice));
@@ -1566,14 +1659,18 @@ int ipnn_get_rows(ipnn_handle* h, const int64_t* row_ids, int64_t n, float* out)
 int ipnn_set_b(ipnn_handle* h, float b)
 {
     if (!h) return FNN_ERR_ARG;
-    IHK(h, hipSetDevice(h->dev)); IHK(h, hipStreamSynchronize(h->st));
+    IHK(h, hipSetDevice(h->dev));
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
+    IHK(h, hipStreamSynchronize(h->st));
     IHK(h, hipMemcpy(h->b, &b, 4, hipMemcpyHostToDevice));
     return FNN_OK;
 }
 int ipnn_get_b(ipnn_handle* h, float* b)
 {
     if (!h || !b) return FNN_ERR_ARG;
-    IHK(h, hipSetDevice(h->dev)); IHK(h, hipStreamSynchronize(h->st));
+    IHK(h, hipSetDevice(h->dev));
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
+    IHK(h, hipStreamSynchronize(h->st));
     IHK(h, hipMemcpy(b, h->b, 4, hipMemcpyDeviceToHost));
     return FNN_OK;
 }
@@ -1597,6 +1694,7 @@ int ipnn_set_layer(ipnn_handle* h, int layer, const float* W, const float* bias)
     for (int r = 0; r < din; ++r) memcpy(&p[(size_t)ip_row_of(h, layer, r) * Dout], &W[(size_t)r * dout], (size_t)dout * 4);
     const int ones_row = layer == 1 ? h->CB + 1 : din;
     memcpy(&p[(size_t)ones_row * Dout], bias, (size_t)dout * 4);
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipStreamSynchronize(h->st));
     IHK(h, hipMemcpy(h->W[layer - 1], p.data(), p.size() * 4, hipMemcpyHostToDevice));
     if (h->bf16) ip_refresh<bf16_t>(h, layer, nullptr, 0.f); else ip_refresh<float>(h, layer, nullptr, 0.f);
@@ -1610,6 +1708,7 @@ int ipnn_get_layer(ipnn_handle* h, int layer, float* W, float* bias)
     IHK(h, hipSetDevice(h->dev));
     const int din = h->d[layer - 1], dout = h->d[layer], Din = h->Dp[layer - 1], Dout = h->Dp[layer];
     std::vector<float> p((size_t)Din * Dout);
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipStreamSynchronize(h->st));
     IHK(h, hipMemcpy(p.data(), h->W[layer - 1], p.size() * 4, hipMemcpyDeviceToHost));
     for (int r = 0; r < din; ++r) memcpy(&W[(size_t)r * dout], &p[(size_t)ip_row_of(h, layer, r) * Dout], (size_t)dout * 4);
@@ -1629,7 +1728,8 @@ int ipnn_train_step(ipnn_handle* h, const int32_t* ids, const float* y, int B, c
     int rc = h->bf16 ? ip_run<bf16_t>(h, ids, y, B, masks, logits_out, nullptr, true)
                      : ip_run<float>(h, ids, y, B, masks, logits_out, nullptr, true);
     if (rc != FNN_OK) return rc;
-    if (loss_sum_out) {
+    if (loss_sum_out) {                                      // (the loss is summed in the update launch: join it)
+        { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
         IHK(h, hipMemcpyAsync(loss_sum_out, h->loss_dev, 4, hipMemcpyDeviceToHost, h->st));
         return ipnn_sync(h);
     }
@@ -1683,6 +1783,7 @@ int ipnn_eval(ipnn_handle* h, const int32_t* ids, const int32_t* y, int64_t N, d
 int ipnn_prof_enable(ipnn_handle* h, int on)
 {
     if (!h) return FNN_ERR_ARG;
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipStreamSynchronize(h->st));
     if (on) { for (auto& kv : h->prof_ev) for (auto& p : kv.second) { hipEventDestroy(p.first); hipEventDestroy(p.second); } h->prof_ev.clear(); }
     h->prof = on != 0;
@@ -1692,6 +1793,7 @@ int ipnn_prof_enable(ipnn_handle* h, int on)
 int ipnn_prof_get(ipnn_handle* h, const char* which, double* avg_ms)
 {
     if (!h || !which || !avg_ms) return FNN_ERR_ARG;
+    { const int jrc = ip_join(h); if (jrc != FNN_OK) return jrc; }
     IHK(h, hipStreamSynchronize(h->st));
     *avg_ms = 0.0;
     if (h->stamps && (!strcmp(which, "fwd") || !strcmp(which, "bwd"))) {      // IPNN_STAMPS=1: the last step's per-layer stamps
