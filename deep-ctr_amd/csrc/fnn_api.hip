@@ -275,13 +275,14 @@ void launch_sort16(fnn_handle* h, const SortArgs& so) {      // split sort: 256-
 // steps run both halves in the same two launches (the data-parallel one with its all-reduce of the slabs
 // between them); the portable split API (fnn_step_begin / _scatter / _end) runs the halves separately.
 template <typename T>
-void launch_step2(fnn_handle* h, bool dense, bool sparse)
+void launch_step2(fnn_handle* h, bool dense, bool sparse, const float* gxp_src = nullptr)
 {
     const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
     const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
     if (h->role_off & 2) dense = false;                     // timing experiments: results are wrong by construction
     if (h->role_off & 4) sparse = false;
-    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    if (gxp_src) sa.gxp = gxp_src;                          // the sparse role reads another shard's gathered gradients (bag EXCHANGE)
     ProfScope ps(h, dense && sparse ? "step2" : (dense ? "step2_dense" : "step2_sparse"), h->st);
     const WgradArgs wa = make_wgrad_args<T>(h, Ba);
     const int nwx = dense ? wgrad_blocks(wa) : 0;
@@ -299,13 +300,14 @@ void launch_step2(fnn_handle* h, bool dense, bool sparse)
 }
 
 template <typename T>
-void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update, float* bucket_dst = nullptr)
+void launch_step3(fnn_handle* h, bool dense, bool sparse, bool update, float* bucket_dst = nullptr, const float* gxp_src = nullptr)
 {
     const int Ba = h->pend_Ba, nxt = h->cur ^ 1;
     const bool have_next = sparse && h->pend_have_next && !(h->role_off & 1);
     if (h->role_off & 2) dense = false;
     if (h->role_off & 4) sparse = false;
-    const ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    ScatArgs sa = make_scat_args(h, h->slot[h->cur], SORT_N);
+    if (gxp_src) sa.gxp = gxp_src;
     {
         ProfScope ps(h, dense && sparse ? "step3" : (dense ? "step3_dense" : "step3_sparse"), h->st);
         const int nred = dense ? (int)((h->nw12 / 4 + 255) / 256) + (int)((h->nw - h->nw12 + h->nbag + 255) / 256) + 1 : 0;
@@ -386,7 +388,13 @@ int ensure_global_ws(fnn_handle* h, int B_g);
 int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g);
 
 // EXCHANGE: all-gather (ids, gx') of every shard, each padded to ldT rows (empty ids), then the sparse-row SGD of the whole
-// global batch in global example order on this rank
+// global batch in global example order on this rank.
+// Bag mode (python/SNN_RBM.py:285-291: ww0[f] -= delta_t, no decay -- a plain sum over the examples): the gathered shards are
+// applied ONE AFTER THE OTHER in rank order with the step's own sparse role (grouping of the shard's ids, then the two levels of
+// the segmented row update reading that shard's gathered deltas): every rank performs the same operations in the same order, so
+// the replicas stay bit-identical to each other, and equal to the single-process step of the global batch up to the rounding of
+// `world` partial sums per row instead of one.
+template <typename T>
 int dp_exchange_sparse(fnn_handle* h, const int32_t* ids, int B)
 {
     const int rows = h->ldT, F = h->F;
@@ -398,7 +406,22 @@ int dp_exchange_sparse(fnn_handle* h, const int32_t* ids, int B)
         if (rc == 0) rc = h->dp_allgather(h->dp_ctx, h->gxp, h->xg_gxp, (int64_t)((size_t)rows * h->K1p * 4), (void*)h->st);
         if (rc != 0) FAIL(h, FNN_ERR_HIP, "data-parallel all-gather failed: " + h->err);
     }
-    return scatter_global_impl(h, h->xg_ids, h->xg_gxp, rows * h->dp_world);
+    if (!h->bag) return scatter_global_impl(h, h->xg_ids, h->xg_gxp, rows * h->dp_world);
+    h->pend_have_next = false;
+    for (int r = 0; r < h->dp_world; ++r) {
+        const int32_t* ids_r = h->xg_ids + (size_t)r * rows * F;
+        fnn_handle::SortSlot& sl = h->slot[h->cur];
+        {
+            ProfScope ps(h, "sort_now", h->st);
+            SortArgs so{ids_r, rows, F, h->n_rows, sl.rec, sl.owner_cnt, F, h->skeys, h->tag_first, sl.tag_shared, next_stamp(h, sl)};
+            launch_sort16(h, so);
+        }
+        const float* gx_r = h->xg_gxp + (size_t)r * rows * h->K1p;
+        launch_step2<T>(h, false, true, gx_r);
+        launch_step3<T>(h, false, true, false, nullptr, gx_r);
+    }
+    HIPCHK(h, hipGetLastError());
+    return FNN_OK;
 }
 
 // The fast path: three role-split launches on the main stream (fnn_step_kernels.hip.h).
@@ -454,7 +477,7 @@ int run_step_fast(fnn_handle* h, const int32_t* ids, const float* y, int B, cons
         }
         if (!local) {
             h->pend_have_next = false;
-            rc = dp_exchange_sparse(h, ids, B);
+            rc = dp_exchange_sparse<T>(h, ids, B);
             if (rc != FNN_OK) return rc;
         }
     }
@@ -607,7 +630,7 @@ int ensure_global_ws(fnn_handle* h, int B_g)
 }
 
 // sparse-row SGD of a global batch in global example order (python/FNN_wnzh.py:299-306): one grouping per field over the
-// global (row, t) keys -- the one-workgroup bitonic sort up to 16,384 keys, rocPRIM's radix sort beyond -- then the
+// global (row, t) keys -- the one-workgroup bitonic sort up to 16,384 keys, the library's own radix sort (metrics.hip) beyond -- then the
 // two-level segmented update reading the gathered gradients
 int scatter_global_impl(fnn_handle* h, const int32_t* ids_g, const float* gxp_g, int B_g)
 {
@@ -707,7 +730,6 @@ int dp_setup(fnn_handle* h, int rank, int world, int sparse_mode)
     if (sparse_mode != FNN_DP_SPARSE_LOCAL && sparse_mode != FNN_DP_SPARSE_EXCHANGE) FAIL(h, FNN_ERR_ARG, "fnn_dp_init: bad sparse_mode");
     if (h->in_step) FAIL(h, FNN_ERR_STATE, "fnn_dp_init inside a step");
     if (sparse_mode == FNN_DP_SPARSE_EXCHANGE) {
-        if (h->bag) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE: FNN_MODE_FM only (the bag update has no order to preserve)");
         if ((int64_t)world * h->ldT > GLOBAL_BATCH_MAX) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE: world * max_batch (rounded up to 256) must be <= 32768");
         if (!(h->fused && mlp_shape_ok(h)) || h->Bmax > SORT_N) FAIL(h, FNN_ERR_ARG, "FNN_DP_SPARSE_EXCHANGE runs on the three-launch path only (max_batch <= 4096, hidden sizes the strip kernel is built for)");
         int rc;
@@ -717,7 +739,7 @@ int dp_setup(fnn_handle* h, int rank, int world, int sparse_mode)
         if (h->xg_gxp) { hipFree(h->xg_gxp); h->xg_gxp = nullptr; }
         if ((rc = alloc_dev(h, &h->xg_ids, rows * world * h->F)) != FNN_OK) return rc;
         if ((rc = alloc_dev(h, &h->xg_gxp, rows * world * h->K1p)) != FNN_OK) return rc;
-        if ((rc = ensure_global_ws(h, (int)rows * world)) != FNN_OK) return rc;
+        if (!h->bag && (rc = ensure_global_ws(h, (int)rows * world)) != FNN_OK) return rc;
     }
     h->dp_rank = rank; h->dp_world = world; h->dp_sparse = sparse_mode;
     h->sorted_ids = nullptr; h->next_ids = nullptr;

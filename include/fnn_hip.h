@@ -172,9 +172,12 @@ int fnn_prefetch_ids(fnn_handle* h, const int32_t* ids, int B);
  * dropout rows must be the same on every rank (they are per batch, not per example, :154,166).
  *   FNN_DP_SPARSE_LOCAL     every rank applies the sparse-row updates of its own shard (replicas drift apart on rows that
  *                           several ranks touch: the throughput mode)
- *   FNN_DP_SPARSE_EXCHANGE  (FNN_MODE_FM) the step also all-gathers (ids, gx') of every shard, each padded to max_batch rows,
- *                           and every rank applies the whole global batch's row updates in global example order: replicas stay
- *                           identical to a single-process run of the global batch (the parity mode; world * max_batch <= 32768)
+ *   FNN_DP_SPARSE_EXCHANGE  the step also all-gathers (ids, gx') of every shard, each padded to max_batch rows, and every rank
+ *                           applies the whole global batch's row updates: replicas stay identical (the parity mode; world *
+ *                           max_batch <= 32768).  FNN_MODE_FM: in global example order, equal to a single-process run of the
+ *                           global batch.  FNN_MODE_BAG (no decay, the update is a sum: python/SNN_RBM.py:285-291): the shards
+ *                           one after the other in rank order -- replicas bit-identical to each other, equal to the
+ *                           single-process run up to the rounding of `world` partial sums per row
  * The collectives are RCCL's: librccl.so.1 is opened at fnn_dp_init (no link-time dependency), the handle owns its communicator. */
 #define FNN_DP_SPARSE_LOCAL    0
 #define FNN_DP_SPARSE_EXCHANGE 1

@@ -267,6 +267,51 @@ def test_two_virtual_ranks_bag_mode_native(built):
         e.close()
 
 
+def test_two_virtual_ranks_bag_mode_exchange(built):
+    """FNN_MODE_BAG under FNN_DP_SPARSE_EXCHANGE: the step all-gathers (ids, delta rows) and every rank applies the shards one
+    after the other in rank order -> the two replicas' tables are bit-identical to each other after two steps, and equal the
+    single-engine steps of the global batches on EVERY row (rows both ranks touch included) up to the rounding of two partial
+    sums per row instead of one."""
+    from test_gpu_parity import make_snn_engine, make_snn_problem
+    G, steps = 900, 2
+    ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(steps * G, seed=23, dup_col=4)
+    full = make_snn_engine(ww0, bb0, p)
+    for s in range(steps):
+        full.train_step(ids[s * G:(s + 1) * G], y[s * G:(s + 1) * G], r1, r2)
+    ref_dense, ref_rows, ref_bb = full.get_dense(), full.get_table(), full.get_bag_bias()
+    full.close()
+    ranks = [make_snn_engine(ww0, bb0, p, max_batch=512) for _ in range(2)]
+    vr = VirtualRanks(2)
+    for r, e in enumerate(ranks):
+        e.dp_init_custom(r, 2, vr.allreduce_for(r), vr.allgather_for(r), sparse='exchange')
+    cut = [slice(0, 500), slice(500, G)]
+
+    def rank_fn(r):
+        def go():
+            for s in range(steps):
+                sl = slice(s * G, (s + 1) * G)
+                ranks[r].train_step(ids[sl][cut[r]], y[sl][cut[r]], r1, r2, b_size=G)
+        return go
+    vr.run([rank_fn(0), rank_fn(1)])
+    assert vr.calls['allreduce'] == steps and vr.calls['allgather'] == 2 * steps
+    touched = np.unique(ids[ids >= 0])
+    change = np.abs(ref_rows[touched] - ww0[touched].astype(np.float32)).max()
+    for e in ranks:
+        got = e.get_table()
+        assert np.abs(got[touched] - ref_rows[touched]).max() <= 3e-4 * change + 1e-7
+        untouched = np.setdiff1d(np.arange(ww0.shape[0]), touched)
+        assert np.array_equal(got[untouched], ref_rows[untouched])
+        d = e.get_dense()
+        for k in ('w1', 'b1', 'w2', 'b2', 'w3'):
+            scale = np.abs(ref_dense[k] - np.asarray(p[k], np.float32)).max() + 1e-12
+            assert np.abs(d[k] - ref_dense[k]).max() <= 5e-4 * scale + 1e-7, k
+        assert np.abs(e.get_bag_bias() - ref_bb).max() <= 5e-4 * np.abs(ref_bb - bb0).max() + 1e-7
+    assert np.array_equal(ranks[0].get_table(), ranks[1].get_table())
+    assert np.array_equal(ranks[0].get_bag_bias(), ranks[1].get_bag_bias())
+    for e in ranks:
+        e.close()
+
+
 def test_two_virtual_ranks_exchange_keeps_replicas_identical(built):
     """EXCHANGE mode: the step all-gathers (ids, gx') of the shards and every rank applies the global batch's row updates in
     global example order -> both tables equal the single-engine run on every row, bit for bit with each other."""

@@ -661,8 +661,8 @@ def make_snn_problem(B, n_rows=600, h0=200, seed=0, dup_col=None, empty=()):
     return ww0, bb0, ids, y, p, r1, r2
 
 
-def make_snn_engine(ww0, bb0, p, prec='f32', lr=0.01, lam1=0.001, h0=200):
-    eng = FNNEngine(F, 0, H1, H2, max_batch=4096, precision=prec, lr=lr, lambda1=lam1, lambda_fm=0.0,
+def make_snn_engine(ww0, bb0, p, prec='f32', lr=0.01, lam1=0.001, h0=200, max_batch=4096):
+    eng = FNNEngine(F, 0, H1, H2, max_batch=max_batch, precision=prec, lr=lr, lambda1=lam1, lambda_fm=0.0,
                     reg_all=True, mode='bag', hidden0=h0)
     eng.set_table(ww0, np.zeros(ww0.shape[0], np.int32), 0.0)
     eng.set_bag_bias(bb0)
