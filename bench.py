@@ -967,10 +967,17 @@ def bench_ipnn(args):
     ms_per_step = dt / args.steps * 1e3
     peak = MFMA_PEAK_TFLOPS[args.precision]
     roof = None
+    if seg.get('fwd', 0) > 0 and seg.get('bwd', 0) > 0:
+        # the narrow tail's forward half rides in the backward tail's launch (k_ip_strip_tail, inside the 'bwd' slot): the two
+        # passes are priced together -- splitting the slots by pass would credit the forward with time it did not spend
+        fl = {'stack': fl['fwd'] + fl['bwd'], 'wgrad': fl['wgrad']}
+        seg = dict(seg, stack=seg['fwd'] + seg['bwd'])
     if seg and any(seg.get(k, 0) > 0 for k in fl):
         dom = max(fl, key=lambda k: seg.get(k, 0.0))
         ach = fl[dom] * B / (seg[dom] * 1e-3) / 1e12
         kname = {'fwd': 'k_ip_strip_fwd (deep stack forward, one launch)', 'bwd': 'k_ip_strip_bwd (deep stack backward-data, one launch)',
+                 'stack': 'k_ip_strip_fwd + k_ip_strip_tail + k_ip_strip_bwd (deep stack forward and backward-data: wide products as pairs of '
+                          '32-example strips, the narrow tail of both passes in one launch of 16-example strips)',
                  'wgrad': 'k_gemm_group (all weight gradients, one launch)'}[dom]
         roof = {'kernel': kname, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': ach / peak, 'traffic': pmc_traffic_ipnn(dom), 'avg_launch_ms': seg[dom], 'algorithmic_per_example': fl[dom]}
@@ -1058,13 +1065,18 @@ def pmc_traffic_ipnn(seg):
     (profiles/*_pmc_traffic_ipnn.json; FETCH_SIZE doubled as in pmc_traffic)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_ipnn.json')))
-    tag = {'fwd': 'k_ip_strip_fwd', 'bwd': 'k_ip_strip_bwd', 'wgrad': 'k_gemm_group'}.get(seg)
-    if not files or not tag:
+    tags = {'fwd': ('k_ip_strip_fwd',), 'bwd': ('k_ip_strip_bwd',), 'wgrad': ('k_gemm_group',),
+            'stack': ('k_ip_strip_fwd', 'k_ip_strip_tail', 'k_ip_strip_bwd')}.get(seg)
+    if not files or not tags:
         return None
-    for name, v in json.load(open(files[-1])).items():
-        if tag in name and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
-            return (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
-    return None
+    tot, hit = 0.0, False
+    for name, v in json.load(open(files[-1])).items():       # 'stack': the sum over its launches (wide and tail instances)
+        if any(t in name for t in tags) and 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
+            tot += (2.0 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+            hit = True
+            if seg != 'stack':
+                break
+    return tot if hit else None
 
 
 def rocprof_avg_ms(kernel, precision='bf16'):

@@ -660,11 +660,11 @@ __device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N,
     if (dbg && threadIdx.x == 0) dbg[13] += (long long)__builtin_amdgcn_s_memtime() - ta;                  // pull (thread 0's share)
 }
 
-template <typename T, int RT, int NF = 4, int NW = STRIP_NW>
-static __global__ __launch_bounds__(64 * NW) void k_ip_strip_fwd(const StripFwdArgs<T> a, const int maxD)
+extern __shared__ __align__(16) unsigned char strip_smem[];   // the strip kernels' dynamic LDS: two tiles [RT * 16][maxD] (+ LDS weight copies)
+template <typename T, int RT, int NF, int NW>
+__device__ __forceinline__ void strip_fwd_body(const StripFwdArgs<T>& a, const int maxD)
 {
     constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, PER = 4 / NF;       // NF < 4: no pairs (the host launches those without StripDuo)
-    extern __shared__ __align__(16) unsigned char strip_smem[];
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
     T* wl = out + (size_t)RT * 16 * maxD;                        // RT = 1: LDS copies of the small products' weights (a.wlds)
@@ -757,12 +757,13 @@ static __global__ __launch_bounds__(64 * NW) void k_ip_strip_fwd(const StripFwdA
         T* t = in; in = out; out = t;
     }
 }
-
 template <typename T, int RT, int NF = 4, int NW = STRIP_NW>
-static __global__ __launch_bounds__(64 * NW) void k_ip_strip_bwd(const StripBwdArgs<T> a, const int maxD)
+static __global__ __launch_bounds__(64 * NW) void k_ip_strip_fwd(const StripFwdArgs<T> a, const int maxD) { strip_fwd_body<T, RT, NF, NW>(a, maxD); }
+
+template <typename T, int RT, int NF, int NW>
+__device__ __forceinline__ void strip_bwd_body(const StripBwdArgs<T>& a, const int maxD)
 {
     constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS, PER = 4 / NF;
-    extern __shared__ __align__(16) unsigned char strip_smem[];
     T* in = reinterpret_cast<T*>(strip_smem);
     T* out = in + (size_t)RT * 16 * maxD;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -818,6 +819,20 @@ static __global__ __launch_bounds__(64 * NW) void k_ip_strip_bwd(const StripBwdA
         STRIP_STAMP(2 + q);
         T* x = in; in = out; out = x;
     }
+}
+template <typename T, int RT, int NF = 4, int NW = STRIP_NW>
+static __global__ __launch_bounds__(64 * NW) void k_ip_strip_bwd(const StripBwdArgs<T> a, const int maxD) { strip_bwd_body<T, RT, NF, NW>(a, maxD); }
+// The narrow tail of a training step, forward then backward, in ONE launch of 16-example strips: what the backward half reads of the
+// forward half -- the output delta (F layout, 16 x 64) and the transposed activations its act' needs -- was stored by this same
+// workgroup, so a drained store queue and a workgroup barrier order them (this CU's L1 holds none of those lines: the forward half
+// never read them; stores write through to the L2).  Saves a launch and the second tile load's cold start.
+template <typename T, int NF, int NW>
+static __global__ __launch_bounds__(64 * NW) void k_ip_strip_tail(const StripFwdArgs<T> fa, const StripBwdArgs<T> ba, const int maxD)
+{
+    strip_fwd_body<T, 1, NF, NW>(fa, maxD);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    strip_bwd_body<T, 1, NF, NW>(ba, maxD);
 }
 
 // Keep-masks [B][d] uint8 (the ABI's layout, reference column order) -> [Dp][ldT] uint8, zero padded,
@@ -1069,6 +1084,7 @@ struct ipnn_handle {
     int mask_side = 0;                               // IPNN_MASK_SIDE=1: the mask transposition on the side stream
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
+    int tail_fuse = 1;                               // IPNN_TAIL_FUSE: training steps run the forward and the backward tail in one launch
     int tail_nf = 1;                                 // IPNN_TAIL_NF: 16-column fragments per item in the 16-example strips of the narrow tail (1 / 2 / 4)
     int tail_nw = 16;                                // IPNN_TAIL_NW: waves per workgroup there (16 with IPNN_TAIL_NF=1 only: 128 registers per lane)
     int ipf_nt = 1024;                               // IPNN_IPF_NT: threads per workgroup of the gather + inner-product launch (512 / 1024)
@@ -1230,6 +1246,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_tail<T, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->strip_attr = true;
         }
     }
@@ -1260,6 +1277,9 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     int maxD2 = 0;
     for (int t = cut; t <= L + 1; ++t) maxD2 = std::max(maxD2, h->Dp[t]);
     const size_t tail_lds = (size_t)2 * 16 * maxD2 * sizeof(T);
+    // training steps: the forward tail rides in the backward tail's launch (k_ip_strip_tail; IPNN_TAIL_FUSE=0: two launches)
+    const bool fuse_tail = tsplit && train && h->tail_fuse && h->tail_nf == 1 && h->tail_nw == 16 && !tail_w_lds;
+    StripFwdArgs<T> s2_fused{};
     if (strip) {
         IpProf ps(h, "fwd");
         StripFwdArgs<T> sa{};
@@ -1291,7 +1311,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
             hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
             const size_t wl2 = lds_weights(s2.Dp, s2.n, s2.wlds);
-            if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wl2, h->st, s2, maxD2);
+            if (fuse_tail) s2_fused = s2;
+            else if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wl2, h->st, s2, maxD2);
             else if (h->tail_nf == 1) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
             else if (h->tail_nf == 2) hipLaunchKernelGGL((k_ip_strip_fwd<T, 1, 2>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
             else hipLaunchKernelGGL((k_ip_strip_fwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wl2, h->st, s2, maxD2);
@@ -1336,7 +1357,8 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             sA.dbg = h->stamp_tail ? sb.dbg : nullptr; sA.rot = h->strip_rot; sA.bottom = 0; sA.finalF = (T*)h->dl[cut - 1]; sA.warm = sb.warm;
             sA.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
             const size_t wlA = lds_weights(sA.Dp, sA.n, sA.wlds);
-            if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wlA, h->st, sA, maxD2);
+            if (fuse_tail) hipLaunchKernelGGL((k_ip_strip_tail<T, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds, h->st, s2_fused, sA, maxD2);
+            else if (h->tail_nf == 1 && h->tail_nw == 16) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 1, 16>), dim3(Ba / 16), dim3(64 * 16), tail_lds + wlA, h->st, sA, maxD2);
             else if (h->tail_nf == 1) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
             else if (h->tail_nf == 2) hipLaunchKernelGGL((k_ip_strip_bwd<T, 1, 2>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
             else hipLaunchKernelGGL((k_ip_strip_bwd<T, 1>), dim3(Ba / 16), dim3(64 * STRIP_NW), tail_lds + wlA, h->st, sA, maxD2);
@@ -1480,6 +1502,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_STRIP_WARM")) h->strip_warm = atoi(e);
     if (const char* e = getenv("IPNN_UPDATE_SIDE")) h->upd_side = atoi(e) != 0;
     if (const char* e = getenv("IPNN_IPF_NT")) h->ipf_nt = atoi(e) == 1024 ? 1024 : 512;
+    if (const char* e = getenv("IPNN_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
     if (const char* e = getenv("IPNN_TAIL_NW")) h->tail_nw = atoi(e) == 16 ? 16 : 8;
     if (const char* e = getenv("IPNN_TAIL_NF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->tail_nf = v; }
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);
