@@ -373,3 +373,38 @@ def test_strip_pairs_are_bit_identical_to_single_strips(built, monkeypatch):
     for t in range(len(Wa)):
         assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t
 
+
+@pytest.mark.parametrize("env", [{'IPNN_TAIL_NF': '4', 'IPNN_TAIL_NW': '8'}, {'IPNN_TAIL_NF': '2'}, {'IPNN_TAIL_NF': '1', 'IPNN_TAIL_NW': '8'},
+                                 {'IPNN_TAIL_FUSE': '0'}, {'IPNN_TAIL_SPLIT': '0'}, {'IPNN_UPDATE_SIDE': '1'}, {'IPNN_IPF_NT': '512'},
+                                 {'IPNN_STRIP_WARM': '0'}])
+def test_launch_forms_of_the_step_are_bit_identical(built, monkeypatch, env):
+    """The forms the FNN_IP_L7 step can be launched in -- the narrow tail's items of 4 / 2 / 1 fragments on 8 / 16 waves, both
+    passes' tails in one launch or two, no tail split at all, the dense update on the side stream with its join deferred to
+    the next call, 512 / 1024 threads per workgroup in the gather -- only regroup the same sums: three train steps with dropout
+    must leave logits, every dense tensor, b and the touched table rows BIT-equal to the default form's.  (The deferred update
+    is also read back between steps here: get_params joins it.)"""
+    hidden = [1000, 800, 600, 400, 200, 100, 50]
+    B, steps = 4096, 3
+    table, ids, y, params, masks, d = problem(B * steps, hidden, seed=78, n_rows=3000, scale=0.05)
+    masks = [(np.random.RandomState(9 + t).uniform(size=(B * steps, d[t])) < 0.5).astype(np.uint8) for t in range(len(hidden) + 1)]
+    res = []
+    for form in (None, env):
+        for k, v in (form or {}).items():
+            monkeypatch.setenv(k, v)
+        eng = IPNNEngine(F, K, hidden, 'relu', max_batch=B, precision='bf16', lr=0.01, keep_prob=0.5)
+        eng.set_params(table, params['b'], params['W'], params['bias'])
+        logits, mids = [], []
+        for s in range(steps):
+            sl = slice(s * B, (s + 1) * B)
+            out = eng.train_step(ids[sl], y[sl], [m[sl] for m in masks], want_logits=True)
+            logits.append(out['logits'].cpu().numpy().copy())
+            if s == 0:
+                mids.append(eng.get_params()[1][0].copy())                # the first layer's weights after ONE step
+        b, Ws, bs = eng.get_params()
+        res.append((np.concatenate(logits), b, Ws, bs, eng.get_rows(np.unique(ids)), mids[0]))
+        eng.close()
+    (la, ba, Wa, bsa, ra, ma), (lb, bb, Wb, bsb, rb, mb) = res
+    assert np.isfinite(la).all() and np.abs(la).max() > 0
+    assert np.array_equal(la, lb) and ba == bb and np.array_equal(ra, rb) and np.array_equal(ma, mb)
+    for t in range(len(Wa)):
+        assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t
