@@ -110,8 +110,8 @@ def main():
                     help='N > 1: who performs the dense all-reduce of the step -- RCCL on the library stream, or the one-shot '
                          'peer-pointer all-reduce inside the update launch (hipIpc-mapped exchange regions)')
     ap.add_argument('--dp-payload', default=None, choices=['slabs', 'bucket'],
-                    help='N > 1, --dp-collective rccl: what the all-reduce carries -- the split-K slabs (2 MB, three launches; the '
-                         'default, or $FNN_DP_PAYLOAD) or the flat bucket (0.5 MB, four launches); p2p always carries the bucket')
+                    help='N > 1, --dp-collective rccl: what the all-reduce carries -- the split-K slabs (2 MB, three launches) or the flat '
+                         'bucket (0.5 MB, four launches: the default at N > 1, or $FNN_DP_PAYLOAD); p2p always carries the bucket')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -309,7 +309,10 @@ def bench_fnn(args, precision, snn):
     if dist is not None:
         from deep_ctr_amd.dp import DataParallelFNN
         try:
-            dpw = DataParallelFNN(eng, sparse=args.dp_sparse if not snn else 'local', payload=args.dp_payload, collective=args.dp_collective)
+            # payload: with real peers the flat bucket is the default here -- a quarter of the slabs' bytes through the collective for
+            # one more launch (2.5 us at world 1, profiles/r03_dp_forms_world1.json); no multi-GPU run has compared the two yet
+            payload = args.dp_payload or os.environ.get('FNN_DP_PAYLOAD') or ('bucket' if world > 1 else None)
+            dpw = DataParallelFNN(eng, sparse=args.dp_sparse, payload=payload, collective=args.dp_collective)
             collective = dpw.collective
         except Exception as e:
             dp_error = '%s: %s' % (type(e).__name__, e)
@@ -481,7 +484,7 @@ def bench_fnn(args, precision, snn):
             cfg = eng.dp_config() if not split else {'payload': 'bucket', 'collective': 'torch.distributed', 'region': 'none'}
             p2p = cfg['collective'] == 'p2p'
             ev = kern_ms.get('empty') or 0.0
-            out['data_parallel'] = {'collective': collective, 'sparse_rows': args.dp_sparse if not snn else 'local',
+            out['data_parallel'] = {'collective': collective, 'sparse_rows': args.dp_sparse,
                                     'payload': cfg['payload'], 'exchange_region': cfg['region'],
                                     'p2p_max_flag_wait_us': eng.dp_p2p_max_wait_us() if p2p else None,     # longest wait for a peer's flag in any step (rank skew)
                                     # event-bracketed slot of the collective on rank 0, the event pair's own cost taken off; for p2p the
