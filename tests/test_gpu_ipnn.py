@@ -408,3 +408,34 @@ def test_launch_forms_of_the_step_are_bit_identical(built, monkeypatch, env):
     assert np.array_equal(la, lb) and ba == bb and np.array_equal(ra, rb) and np.array_equal(ma, mb)
     for t in range(len(Wa)):
         assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t
+
+
+@pytest.mark.parametrize("hidden,B", [([640, 500, 300, 70], 1000), ([400, 400, 200], 300), ([1000, 800, 600, 400, 200], 2048),
+                                      ([900, 130, 700, 60], 777)])
+def test_tail_split_forms_on_other_stacks(built, monkeypatch, hidden, B):
+    """Other stacks and batch lengths than FNN_IP_L7's (a different cut between wide and narrow products, one narrow product
+    only, a narrow layer BETWEEN wide ones -- then no suffix is cut off but the trailing one --, ragged last strips): the default
+    form (tail of 16-example strips, one fragment per wave on 16 waves, both passes in one launch) against round 2's single
+    launch per pass (IPNN_TAIL_SPLIT=0), bit for bit over two steps with dropout."""
+    steps = 2
+    table, ids, y, params, masks, d = problem(B * steps, hidden, seed=B, n_rows=2000, scale=0.05)
+    masks = [(np.random.RandomState(3 + t).uniform(size=(B * steps, d[t])) < 0.5).astype(np.uint8) for t in range(len(hidden) + 1)]
+    res = []
+    for split in ('1', '0'):
+        monkeypatch.setenv('IPNN_TAIL_SPLIT', split)
+        eng = IPNNEngine(F, K, hidden, 'tanh', max_batch=B, precision='bf16', lr=0.01, keep_prob=0.5)
+        eng.set_params(table, params['b'], params['W'], params['bias'])
+        logits = []
+        for s in range(steps):
+            sl = slice(s * B, (s + 1) * B)
+            out = eng.train_step(ids[sl], y[sl], [m[sl] for m in masks], want_logits=True)
+            logits.append(out['logits'].cpu().numpy().copy())
+        pr = eng.predict(ids[:B]).cpu().numpy().copy()
+        b, Ws, bs = eng.get_params()
+        res.append((np.concatenate(logits), b, Ws, bs, eng.get_rows(np.unique(ids)), pr))
+        eng.close()
+    (la, ba, Wa, bsa, ra, pa), (lb, bb, Wb, bsb, rb, pb) = res
+    assert np.isfinite(la).all() and np.abs(la).max() > 0
+    assert np.array_equal(la, lb) and ba == bb and np.array_equal(ra, rb) and np.array_equal(pa, pb)
+    for t in range(len(Wa)):
+        assert np.array_equal(Wa[t], Wb[t]) and np.array_equal(bsa[t], bsb[t]), t
