@@ -47,6 +47,7 @@ struct fnn_handle {
     int scat2_wgs = 256;        // workgroups walking the multi-chunk segments in launch 3
     bool bf16 = false;          // FNN_PREC_BF16: 2-byte elements
     bool split = false;         // FNN_PREC_BF16X3: 4-byte elements (bs16_t), the f32 mode's layouts
+    int wt_stores = 7;                                                 // FNN_WT_STORES (MlpArgs::wt; 0: plain stores): how the strip kernel's training outputs leave
     bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
     float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
     bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
@@ -233,13 +234,14 @@ template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids
                       m1 ? m1 : h->ones_u8, m2 ? m2 : h->ones_u8, h->cfg.act, train ? ACT_TANH : h->cfg.act,
                       h->H1, h->H2, train ? 1 : 0,
                       (T*)h->xpT, (T*)h->d1T, (T*)h->d2T, (T*)h->dl1T, (T*)h->dl2T, (T*)h->dl3T, h->ldT,
-                      h->gxp, p_out, h->loss_t, h->err_flag, h->bb0, h->rw, (T*)h->dlxT, nullptr};
+                      h->gxp, p_out, h->loss_t, h->err_flag, h->bb0, h->rw, (T*)h->dlxT, nullptr, h->wt_stores};
 }
 template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int F) {
     constexpr int PAD = 16 / (int)sizeof(T);
     constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
     size_t n = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
     if (bag) n += (size_t)16 * 64 * CX * sizeof(float) + (size_t)16 * F * sizeof(int);
+    else n += (size_t)4 * 16 * 36 * sizeof(float);            // the waves' blocks for regrouping gx' into whole lines (mlp_body, P4)
     return n;
 }
 template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
@@ -802,6 +804,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->xdim = 1 + h->F * h->K;
     h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
     h->bag = cfg->mode == FNN_MODE_BAG;
+    if (const char* e = getenv("FNN_WT_STORES")) h->wt_stores = atoi(e);
     if (h->bag) { h->rw = cfg->h0; h->K = cfg->h0; h->xdim = cfg->h0; h->K1p = rup(cfg->h0 + 1, 64); }
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     h->N2max = SORT_N; while (h->N2max < h->Bmax) h->N2max <<= 1;    // the three-launch path groups SORT_N slots per field whatever max_batch is

@@ -190,6 +190,26 @@ __device__ inline void store4(bf16_t* p, float a, float b, float c, float d) {
 __device__ inline void store4(bs16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<u32x4*>(p) = u32x4{bs_pack(a), bs_pack(b), bs_pack(c), bs_pack(d)};
 }
+// The same stores written THROUGH the XCD's L2 (sc1): what a kernel leaves dirty in its L2s is written back at its end, before the
+// next launch can start (MI355X_MICROARCH.md, cost cell `boundary`: + bytes / 6 TB/s); the strip kernel's 13.6 MB of transposed
+// activations and gx' leave while it still computes instead (MlpArgs::wt; measured on one box each: 40.9 -> 39.6 us per step; the same
+// treatment of the split-K slabs and of step 3's outputs changed nothing, of the updated table rows -- scalar 4-byte stores, and the
+// next launch re-reads hot rows -- cost 1.8 us)
+__device__ inline void store4_wt(float* p, float a, float b, float c, float d) {
+    const f32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ inline void store4_wt(bf16_t* p, float a, float b, float c, float d) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    u2 w; __builtin_memcpy(&w, &v, 8);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+}
+__device__ inline void store4_wt(bs16_t* p, float a, float b, float c, float d) {
+    const u32x4 v = {bs_pack(a), bs_pack(b), bs_pack(c), bs_pack(d)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ inline void store1_wt(float* p, float a) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(a) : "memory"); }
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains every global
 // load and store in flight (s_waitcnt vmcnt(0)), which would serialise the strip kernel's
 // weight prefetch and its activation stores behind each phase barrier; the waves of a strip
@@ -843,6 +863,7 @@ template <typename T> struct MlpArgs {
     float *gxp, *p_out, *loss_t; int* err;
     // embedding-bag input layer (SNN fine-tune, python/SNN_RBM.py:238-291); unused in FM mode
     const float* bb0; int rw; T* dlxT; float* gx_raw;
+    int wt;                         // bits: 1 the transposed activations by write-through stores (store4_wt), 2 gx' too, 4 gx' regrouped into whole lines
 #ifdef FNN_STAMPS
     long long* dbg;                 // diagnostic build only: per-workgroup phase time stamps
 #endif
@@ -931,6 +952,8 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int t0 = blk * 16;
     const int F = a.F, K = a.K, B = a.B, ldT = a.ldT;
+    const bool wt = (a.wt & 1) != 0, wtg = (a.wt & 2) != 0;
+#define ST4(p, x0, x1, x2, x3) do { if (wt) store4_wt(p, x0, x1, x2, x3); else store4(p, x0, x1, x2, x3); } while (0)
     FNN_STAMP_RT(14);
     FNN_STAMP(0);
 
@@ -1021,8 +1044,8 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (a.train) {
             for (int e = tid; e < K1p * 4; e += 256) {
                 const int c = e >> 2, tq = e & 3;
-                store4(a.xpT + ft_off<T>(c, t0 + 4 * tq, ldT), (float)sx[(4 * tq) * LX + c], (float)sx[(4 * tq + 1) * LX + c],
-                       (float)sx[(4 * tq + 2) * LX + c], (float)sx[(4 * tq + 3) * LX + c]);
+                ST4(a.xpT + ft_off<T>(c, t0 + 4 * tq, ldT), (float)sx[(4 * tq) * LX + c], (float)sx[(4 * tq + 1) * LX + c],
+                    (float)sx[(4 * tq + 2) * LX + c], (float)sx[(4 * tq + 3) * LX + c]);
             }
         }
     } else {
@@ -1064,7 +1087,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (a.train) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                store4(a.xpT + ft_off<T>(c0 + j, t0 + 4 * tq, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
+                ST4(a.xpT + ft_off<T>(c0 + j, t0 + 4 * tq, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
         }
     }
     for (int e = tid; e < 16 * (K1p - F * SLOT); e += 256) {       // pad columns of the tile
@@ -1116,7 +1139,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (a.train) {
 #pragma unroll
             for (int i = 0; i < C1; ++i)
-                store4(a.d1T + ft_off<T>((wave * C1 + i) * 16 + lr, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
+                ST4(a.d1T + ft_off<T>((wave * C1 + i) * 16 + lr, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
         }
     }
     lds_barrier();
@@ -1164,7 +1187,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (a.train) {
 #pragma unroll
             for (int i = 0; i < C2; ++i)
-                store4(a.d2T + ft_off<T>((wave * C2 + i) * 16 + lr, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
+                ST4(a.d2T + ft_off<T>((wave * C2 + i) * 16 + lr, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
         }
     }
 #pragma unroll
@@ -1206,7 +1229,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             v[r] = d3[r] * w3m * (1.0f - d2v[i][r] * d2v[i][r]);
             sdl2[(4 * lq + r) * L2 + col] = (T)v[r];
         }
-        store4(a.dl2T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+        ST4(a.dl2T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
     }
     lds_barrier();
     FNN_STAMP(6);
@@ -1247,7 +1270,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 v[r] = acc[i][r] * m * dact_apply(ac1, d1v[i][r]) * rv[r];
                 sdl1[(4 * lq + r) * L1 + col] = (T)v[r];
             }
-            store4(a.dl1T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+            ST4(a.dl1T + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
         }
     }
     lds_barrier();
@@ -1268,6 +1291,31 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             }
         } else wring_product<T, NKH1, CX, DR4>(acc, r4, ap, a.w1, wave * CX, lane);
         FNN_STAMP(9);
+        if constexpr (!BAG && CX % 2 == 0) {
+            if (a.wt & 4) {
+                // gx' [example][K1p] f32 in whole 128-byte lines: two fragments (32 columns) at a time through a wave-private LDS
+                // block -- the MFMA layout has a lane on 4 ROWS of one column (sixteen 4-byte stores per lane,
+                // 64-byte pieces per instruction); regrouped, a lane holds 4 columns of one row (four 16-byte stores per lane)
+                float* sg = sz + 64 + wave * (16 * 36);           // behind the tiles (mlp_lds_bytes: FM mode keeps 4 x 2,304 bytes there)
+#pragma unroll
+                for (int ip = 0; ip < CX / 2; ++ip) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sg[(4 * lq + r) * 36 + f * 16 + lr] = acc[2 * ip + f][r];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int row = hh * 8 + (lane >> 3), c4 = lane & 7;
+                        const float4 v = *reinterpret_cast<const float4*>(sg + row * 36 + 4 * c4);
+                        float* dst = a.gxp + (size_t)(t0 + row) * K1p + (wave * CX + 2 * ip) * 16 + 4 * c4;
+                        if (wtg) store4_wt(dst, v.x, v.y, v.z, v.w); else store4(dst, v.x, v.y, v.z, v.w);
+                    }
+                }
+                FNN_STAMP(10);
+                FNN_STAMP_RT(15);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < CX; ++i) {
             const int col = (wave * CX + i) * 16 + lr;
@@ -1278,18 +1326,19 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                     const int row = 4 * lq + r;
                     const float xv = sxf[row * K1p + col];
                     v[r] = acc[i][r] * xv * (1.0f - xv);          // sxf is 0 beyond column rw and row B
-                    a.gxp[(size_t)(t0 + row) * K1p + col] = v[r];
+                    if (wtg) store1_wt(a.gxp + (size_t)(t0 + row) * K1p + col, v[r]); else a.gxp[(size_t)(t0 + row) * K1p + col] = v[r];
                     if (a.gx_raw) a.gx_raw[(size_t)(t0 + row) * K1p + col] = acc[i][r];
                 }
-                store4(a.dlxT + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
+                ST4(a.dlxT + ft_off<T>(col, t0 + 4 * lq, ldT), v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r];
+                for (int r = 0; r < 4; ++r) { if (wtg) store1_wt(a.gxp + (size_t)(t0 + 4 * lq + r) * K1p + col, acc[i][r]); else a.gxp[(size_t)(t0 + 4 * lq + r) * K1p + col] = acc[i][r]; }
             }
         }
     }
     FNN_STAMP(10);
     FNN_STAMP_RT(15);
+#undef ST4
 }
 
 template <typename T, int C1, int C2, int CX>
