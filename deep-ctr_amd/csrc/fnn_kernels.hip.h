@@ -209,6 +209,11 @@ __device__ inline void store4_wt(bs16_t* p, float a, float b, float c, float d) 
     const u32x4 v = {bs_pack(a), bs_pack(b), bs_pack(c), bs_pack(d)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
+template <typename V> __device__ inline void store16_wt(void* p, const V& v) {          // any 16-byte value
+    static_assert(sizeof(V) == 16, "store16_wt: 16-byte values");
+    u32x4 w; __builtin_memcpy(&w, &v, 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+}
 __device__ inline void store1_wt(float* p, float a) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(a) : "memory"); }
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains every global
 // load and store in flight (s_waitcnt vmcnt(0)), which would serialise the strip kernel's
@@ -427,6 +432,16 @@ struct EpiF32 {                               // plain float output (gx', split-
     }
 };
 
+// The split-K slabs of a grouped launch (k_gemm_group): the same values, but a wave's 16 x 64 block of four fragments goes
+// through a wave-private LDS tile and leaves as 16-byte write-through stores of whole 256-byte row pieces (the MFMA layout has a
+// lane on 4 rows of one column: sixteen 4-byte stores per fragment row tile, 64-byte pieces, and 30 MB left dirty in the L2s for
+// the end of the launch to write back).  Needs gemm_f32w_lds() bytes of dynamic LDS and TN = 4.
+struct EpiF32W {
+    static constexpr bool TILE = false;
+    float* out; int ld; size_t zstride;
+};
+constexpr size_t gemm_f32w_lds() { return (size_t)4 * 16 * 68 * sizeof(float); }
+
 template <typename T, int NT, typename Epi>
 static __global__ __launch_bounds__(256) void k_gemm(const T* __restrict__ A, int lda,
                                               const T* __restrict__ Bft, int klen, Epi epi)
@@ -463,6 +478,30 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const int rt
                                               unsigned char* gemm_smem, const Epi& epi, const int z)
 {
     const int rq = 4 * (lane >> 4), cl = lane & 15;              // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    if constexpr (std::is_same<Epi, EpiF32W>::value) {
+        static_assert(TN == 4, "EpiF32W: four fragments per row tile");
+        float* tile = reinterpret_cast<float*>(gemm_smem) + (size_t)wave * 16 * 68;     // [16][64 + 4]: conflict-free both ways
+        float* o = epi.out + (size_t)z * epi.zstride;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(rq + r) * 68 + n * 16 + cl] = acc[m][n][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 4, c4 = idx & 15;
+                const float4 v = *reinterpret_cast<const float4*>(tile + row * 68 + 4 * c4);
+                store16_wt(o + (size_t)((rt0 + m) * 16 + row) * epi.ld + ct0 * 16 + 4 * c4, v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else
     if constexpr (Epi::TILE) {
         // Activation-like output in both fragment-tiled orientations.  xT (rows = columns of C,
         // k = rows of C): the lane's 4 accumulator rows are 4 consecutive k -> one 8-byte store.
@@ -592,8 +631,8 @@ static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g
         local = (cls < rm ? cls * (qd + 1) : rm * (qd + 1) + (cls - rm) * qd) + k;
     }
     const int bx = local % pr.gx, by = (local / pr.gx) % pr.gy, bz = local / (pr.gx * pr.gy);
-    const EpiF32 e{pr.out, pr.ldo, g.zstride};
-    gemm_ft_body<T, TM, TN, EpiF32>(static_cast<const T*>(pr.A), static_cast<const T*>(pr.B), pr.mt16, pr.nt16, pr.nkt_all, pr.nkt, e, bx, by, bz);
+    const EpiF32W e{pr.out, pr.ldo, g.zstride};
+    gemm_ft_body<T, TM, TN, EpiF32W>(static_cast<const T*>(pr.A), static_cast<const T*>(pr.B), pr.mt16, pr.nt16, pr.nkt_all, pr.nkt, e, bx, by, bz);
 }
 
 // dynamic LDS of k_gemm_ft for a tile epilogue: 4 wave-private [16][16 TN + 8] tiles

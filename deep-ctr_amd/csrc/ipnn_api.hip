@@ -118,7 +118,7 @@ static __global__ __launch_bounds__(NT) void k_ip_fwd(const IpFwdArgs a, T* __re
         for (int e = tid; e < 16 * FS / 4; e += NT) {
             const int r = (4 * e) / FS, c = (4 * e) % FS;
             const float* q = se + r * FSP + (c >> 4) * SP + (c & 15);
-            *reinterpret_cast<float4*>(emb + (size_t)t0 * FS + 4 * e) = make_float4(q[0], q[1], q[2], q[3]);
+            store16_wt(emb + (size_t)t0 * FS + 4 * e, make_float4(q[0], q[1], q[2], q[3]));
         }
     const float bval = *a.b;
     // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + NWV i; 8 columns at a time: their pair indices,
@@ -176,12 +176,12 @@ static __global__ __launch_bounds__(NT) void k_ip_fwd(const IpFwdArgs a, T* __re
         frag fv;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) fv[x] = (T)sa[r * a.D0p + g * EPL + x];
-        *reinterpret_cast<frag*>(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p)) = fv;
+        store16_wt(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p), fv);
     }
     for (int e = tid; e < a.D0p * 4; e += NT) {
         const int c = e >> 2, tq = e & 3;
-        store4(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
-               sa[(4 * tq + 2) * a.D0p + c], sa[(4 * tq + 3) * a.D0p + c]);
+        store4_wt(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
+                  sa[(4 * tq + 2) * a.D0p + c], sa[(4 * tq + 3) * a.D0p + c]);
     }
 }
 
@@ -870,7 +870,7 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     if (c0 + cc < a.Dp[t])
     {
         const unsigned* w = reinterpret_cast<const unsigned*>(&s[cc][16 * q]);
-        *reinterpret_cast<uint4*>(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT)) = make_uint4(w[0], w[1], w[2], w[3]);
+        store16_wt(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT), make_uint4(w[0], w[1], w[2], w[3]));
     }
 }
 
@@ -1033,8 +1033,8 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
             w.w = opt_step(u.adam, w.w, g.w, m.w, v.w, u.lr, u.beta1, u.beta2, u.eps);
             *reinterpret_cast<float4*>(u.Wm[t] + j) = m; *reinterpret_cast<float4*>(u.Wv[t] + j) = v;
         } else { w.x -= u.lr * g.x; w.y -= u.lr * g.y; w.z -= u.lr * g.z; w.w -= u.lr * g.w; }
-        *reinterpret_cast<float4*>(u.W[t] + j) = w;
-        store4(wb + ft_off<T>(r, c, Dout), w.x, w.y, w.z, w.w);
+        store16_wt(u.W[t] + j, w);                              // (written through: see store4_wt)
+        store4_wt(wb + ft_off<T>(r, c, Dout), w.x, w.y, w.z, w.w);
         const int rl = r - r0;
         sT[cq][rl] = (T)w.x; sT[cq + 1][rl] = (T)w.y; sT[cq + 2][rl] = (T)w.z; sT[cq + 3][rl] = (T)w.w;
     }
@@ -1042,7 +1042,7 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     T* wf = static_cast<T*>(u.wf[t]);
     for (int e = threadIdx.x; e < 64 * (64 / EPL); e += 256) {      // (column, group of EPL rows): one lane slot of wf
         const int cl = e & 63, g8 = e >> 6;
-        *reinterpret_cast<frag*>(wf + ft_off<T>(c0 + cl, r0 + g8 * EPL, Din)) = *reinterpret_cast<const frag*>(&sT[cl][g8 * EPL]);
+        store16_wt(wf + ft_off<T>(c0 + cl, r0 + g8 * EPL, Din), *reinterpret_cast<const frag*>(&sT[cl][g8 * EPL]));
     }
 }
 
@@ -1432,7 +1432,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                 g.wg0[i] = wg; wg += pr.gx * pr.gy * sk;
             }
             g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride; g.xcd = h->group_xcd;
-            hipLaunchKernelGGL((k_gemm_group<T, 4, 4>), dim3(wg), dim3(256), 0, h->st, g);
+            hipLaunchKernelGGL((k_gemm_group<T, 4, 4>), dim3(wg), dim3(256), gemm_f32w_lds(), h->st, g);
         } else {
         size_t off = 0;
         for (int t = 1; t <= L + 1; ++t) {
