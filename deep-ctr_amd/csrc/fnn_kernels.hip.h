@@ -214,6 +214,14 @@ template <typename V> __device__ inline void store16_wt(void* p, const V& v) {  
     u32x4 w; __builtin_memcpy(&w, &v, 16);
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
 }
+// the same with the policy as a (wave-uniform) argument: every launch that writes through can be run with plain stores, and a test
+// holds the two forms bit-equal (a write-through store that the next launch does not see in time would show there)
+template <typename V> __device__ inline void store16_sel(const bool wt, void* p, const V& v) {
+    if (wt) store16_wt(p, v); else { u32x4 w; __builtin_memcpy(&w, &v, 16); *reinterpret_cast<u32x4*>(p) = w; }
+}
+template <typename P> __device__ inline void store4_sel(const bool wt, P* p, float a, float b, float c, float d) {
+    if (wt) store4_wt(p, a, b, c, d); else store4(p, a, b, c, d);
+}
 __device__ inline void store1_wt(float* p, float a) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(a) : "memory"); }
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains every global
 // load and store in flight (s_waitcnt vmcnt(0)), which would serialise the strip kernel's
@@ -438,7 +446,7 @@ struct EpiF32 {                               // plain float output (gx', split-
 // the end of the launch to write back).  Needs gemm_f32w_lds() bytes of dynamic LDS and TN = 4.
 struct EpiF32W {
     static constexpr bool TILE = false;
-    float* out; int ld; size_t zstride;
+    float* out; int ld; size_t zstride; bool wt;
 };
 constexpr size_t gemm_f32w_lds() { return (size_t)4 * 16 * 68 * sizeof(float); }
 
@@ -495,7 +503,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const int rt
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 4, c4 = idx & 15;
                 const float4 v = *reinterpret_cast<const float4*>(tile + row * 68 + 4 * c4);
-                store16_wt(o + (size_t)((rt0 + m) * 16 + row) * epi.ld + ct0 * 16 + 4 * c4, v);
+                store16_sel(epi.wt, o + (size_t)((rt0 + m) * 16 + row) * epi.ld + ct0 * 16 + 4 * c4, v);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -613,7 +621,7 @@ static __global__ __launch_bounds__(256) void k_gemm_ft(const T* __restrict__ A,
 // problem q owns workgroups wg0[q] .. wg0[q+1]-1, laid out (x fastest, then y, then the K split).
 constexpr int GEMM_GROUP_MAX = 9;
 struct GemmGroupProb { const void* A; const void* B; float* out; int mt16, nt16, nkt_all, nkt, ldo, gx, gy; };
-struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int wg0[GEMM_GROUP_MAX + 1]; int n; size_t zstride; int xcd; };
+struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int wg0[GEMM_GROUP_MAX + 1]; int n; size_t zstride; int xcd; int wt; };   // wt: slabs written through
 
 template <typename T, int TM, int TN>
 static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g)
@@ -631,7 +639,7 @@ static __global__ __launch_bounds__(256) void k_gemm_group(const GemmGroupArgs g
         local = (cls < rm ? cls * (qd + 1) : rm * (qd + 1) + (cls - rm) * qd) + k;
     }
     const int bx = local % pr.gx, by = (local / pr.gx) % pr.gy, bz = local / (pr.gx * pr.gy);
-    const EpiF32W e{pr.out, pr.ldo, g.zstride};
+    const EpiF32W e{pr.out, pr.ldo, g.zstride, g.wt != 0};
     gemm_ft_body<T, TM, TN, EpiF32W>(static_cast<const T*>(pr.A), static_cast<const T*>(pr.B), pr.mt16, pr.nt16, pr.nkt_all, pr.nkt, e, bx, by, bz);
 }
 

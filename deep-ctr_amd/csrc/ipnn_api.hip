@@ -63,6 +63,7 @@ struct IpFwdArgs {
     const int32_t* ids; int B, F, K; const float* table16; int64_t n_rows; const float* b;
     const uint8_t* mask; int d0; float inv_keep; int act; int D0p, ldT; int* err;
     int skip;                   // diagnostics (IPNN_FWD_SKIP bits: 1 gather, 2 embedding store, 4 compute, 8 output stores); 0 in production
+    bool wt;                    // outputs written through (IPNN_WT=0: plain stores; see store4_wt in fnn_kernels.hip.h)
 };
 
 // gather of 16 examples' rows into an LDS tile [16][F*16]: all ids of a batch of 4 elements per thread first, then all
@@ -118,7 +119,7 @@ static __global__ __launch_bounds__(NT) void k_ip_fwd(const IpFwdArgs a, T* __re
         for (int e = tid; e < 16 * FS / 4; e += NT) {
             const int r = (4 * e) / FS, c = (4 * e) % FS;
             const float* q = se + r * FSP + (c >> 4) * SP + (c & 15);
-            store16_wt(emb + (size_t)t0 * FS + 4 * e, make_float4(q[0], q[1], q[2], q[3]));
+            store16_sel(a.wt, emb + (size_t)t0 * FS + 4 * e, make_float4(q[0], q[1], q[2], q[3]));
         }
     const float bval = *a.b;
     // a thread owns columns c = (tid & 63) + 64 k and rows r = (tid >> 6) + NWV i; 8 columns at a time: their pair indices,
@@ -176,11 +177,11 @@ static __global__ __launch_bounds__(NT) void k_ip_fwd(const IpFwdArgs a, T* __re
         frag fv;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) fv[x] = (T)sa[r * a.D0p + g * EPL + x];
-        store16_wt(a0 + ft_off<T>(t0 + r, g * EPL, a.D0p), fv);
+        store16_sel(a.wt, a0 + ft_off<T>(t0 + r, g * EPL, a.D0p), fv);
     }
     for (int e = tid; e < a.D0p * 4; e += NT) {
         const int c = e >> 2, tq = e & 3;
-        store4_wt(a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
+        store4_sel(a.wt, a0T + ft_off<T>(c, t0 + 4 * tq, a.ldT), sa[(4 * tq) * a.D0p + c], sa[(4 * tq + 1) * a.D0p + c],
                   sa[(4 * tq + 2) * a.D0p + c], sa[(4 * tq + 3) * a.D0p + c]);
     }
 }
@@ -839,7 +840,7 @@ static __global__ __launch_bounds__(64 * NW) void k_ip_strip_tail(const StripFwd
 // for every layer in one launch; layer 0's columns are mapped to the slot layout on the way.
 struct MaskTArgs {
     const uint8_t* src[IPNN_MAX_HIDDEN + 1]; uint8_t* dst[IPNN_MAX_HIDDEN + 1]; int d[IPNN_MAX_HIDDEN + 1], Dp[IPNN_MAX_HIDDEN + 1];
-    int tile0[IPNN_MAX_HIDDEN + 2]; int n; const int* ref0; int B, Ba, ldT;
+    int tile0[IPNN_MAX_HIDDEN + 2]; int n; const int* ref0; int B, Ba, ldT; bool wt;
 };
 static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
 {
@@ -870,7 +871,7 @@ static __global__ __launch_bounds__(256) void k_mask_T(const MaskTArgs a)
     if (c0 + cc < a.Dp[t])
     {
         const unsigned* w = reinterpret_cast<const unsigned*>(&s[cc][16 * q]);
-        store16_wt(a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT), make_uint4(w[0], w[1], w[2], w[3]));
+        store16_sel(a.wt, a.dst[t] + mask_off(c0 + cc, t0 + 16 * q, a.ldT), make_uint4(w[0], w[1], w[2], w[3]));
     }
 }
 
@@ -937,6 +938,7 @@ static __global__ void k_adam_table(float* __restrict__ tab, float* __restrict__
 // One launch for the whole stack: W_t <- W_t - lr * (sum of its split-K slabs), both tiled shadows
 // refreshed; the last workgroup applies the bias-of-z1 gradient and reduces the per-example losses.
 struct IpUpdArgs {
+    bool wt;                                         // weights and shadows written through (IPNN_WT)
     float* W[IPNN_MAX_HIDDEN + 1]; void* wf[IPNN_MAX_HIDDEN + 1]; void* wb[IPNN_MAX_HIDDEN + 1];
     size_t off[IPNN_MAX_HIDDEN + 2];                 // element offset of every layer in a slab; off[n] = total
     int Din[IPNN_MAX_HIDDEN + 1], Dout[IPNN_MAX_HIDDEN + 1], sk[IPNN_MAX_HIDDEN + 1]; int n;
@@ -1033,8 +1035,8 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
             w.w = opt_step(u.adam, w.w, g.w, m.w, v.w, u.lr, u.beta1, u.beta2, u.eps);
             *reinterpret_cast<float4*>(u.Wm[t] + j) = m; *reinterpret_cast<float4*>(u.Wv[t] + j) = v;
         } else { w.x -= u.lr * g.x; w.y -= u.lr * g.y; w.z -= u.lr * g.z; w.w -= u.lr * g.w; }
-        store16_wt(u.W[t] + j, w);                              // (written through: see store4_wt)
-        store4_wt(wb + ft_off<T>(r, c, Dout), w.x, w.y, w.z, w.w);
+        store16_sel(u.wt, u.W[t] + j, w);                       // (written through: see store4_wt)
+        store4_sel(u.wt, wb + ft_off<T>(r, c, Dout), w.x, w.y, w.z, w.w);
         const int rl = r - r0;
         sT[cq][rl] = (T)w.x; sT[cq + 1][rl] = (T)w.y; sT[cq + 2][rl] = (T)w.z; sT[cq + 3][rl] = (T)w.w;
     }
@@ -1042,7 +1044,7 @@ static __global__ __launch_bounds__(256) void k_ip_update_all(const IpUpdArgs u)
     T* wf = static_cast<T*>(u.wf[t]);
     for (int e = threadIdx.x; e < 64 * (64 / EPL); e += 256) {      // (column, group of EPL rows): one lane slot of wf
         const int cl = e & 63, g8 = e >> 6;
-        store16_wt(wf + ft_off<T>(c0 + cl, r0 + g8 * EPL, Din), *reinterpret_cast<const frag*>(&sT[cl][g8 * EPL]));
+        store16_sel(u.wt, wf + ft_off<T>(c0 + cl, r0 + g8 * EPL, Din), *reinterpret_cast<const frag*>(&sT[cl][g8 * EPL]));
     }
 }
 
@@ -1084,6 +1086,7 @@ struct ipnn_handle {
     int mask_side = 0;                               // IPNN_MASK_SIDE=1: the mask transposition on the side stream
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
+    bool wt = true;                                  // IPNN_WT=0: plain stores where the launches write through by default
     int tail_fuse = 1;                               // IPNN_TAIL_FUSE: training steps run the forward and the backward tail in one launch
     int tail_nf = 1;                                 // IPNN_TAIL_NF: 16-column fragments per item in the 16-example strips of the narrow tail (1 / 2 / 4)
     int tail_nw = 16;                                // IPNN_TAIL_NW: waves per workgroup there (16 with IPNN_TAIL_NF=1 only: 128 registers per lane)
@@ -1162,7 +1165,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                 ma.src[t] = masks[t]; ma.dst[t] = h->maskT[t]; ma.d[t] = h->d[t]; ma.Dp[t] = h->Dp[t]; ma.tile0[t] = tiles;
                 tiles += (Ba / 64) * (h->Dp[t] / 64);
             }
-            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT;
+            ma.tile0[L + 1] = tiles; ma.n = L + 1; ma.ref0 = h->ref0; ma.B = B; ma.Ba = Ba; ma.ldT = ldT; ma.wt = h->wt;
             // on the MAIN stream by default: a cross-stream event on the way into the first strip kernel costs more (10-20 us of
             // wait resolution, measured on the kernel trace) than the 10 us the transposition takes in line.  (Round 3 also tried
             // transposing the NEXT step's masks ahead, on the side stream -- beside the strips: 0.265 -> 0.270 ms per step, at the end
@@ -1184,7 +1187,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     {
         IpProf ps(h, "ip_fwd");
         IpFwdArgs fa{h->P, ids, B, F, h->K, h->table16, h->n_rows, h->b, (train && masks) ? masks[0] : nullptr, h->d[0],
-                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag, h->fwd_skip};
+                     (train && masks) ? inv_keep : 1.0f, h->cfg.act, h->Dp[0], ldT, h->err_flag, h->fwd_skip, h->wt};
         if (h->ipf_nt == 1024) hipLaunchKernelGGL((k_ip_fwd<T, 1024>), dim3(Ba / 16), dim3(1024), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
         else hipLaunchKernelGGL((k_ip_fwd<T>), dim3(Ba / 16), dim3(IPF_NT), lds_ip, h->st, fa, (T*)h->a[0], (T*)h->aT[0], train ? h->emb : nullptr);
     }
@@ -1431,7 +1434,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
                 pr.nkt_all = ldT / KS; pr.nkt = Ba / KS / sk; pr.ldo = N; pr.gx = (M + 127) / 128; pr.gy = (N + 127) / 128;
                 g.wg0[i] = wg; wg += pr.gx * pr.gy * sk;
             }
-            g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride; g.xcd = h->group_xcd;
+            g.wg0[L + 1] = wg; g.n = L + 1; g.zstride = h->slab_stride; g.xcd = h->group_xcd; g.wt = h->wt;
             hipLaunchKernelGGL((k_gemm_group<T, 4, 4>), dim3(wg), dim3(256), gemm_f32w_lds(), h->st, g);
         } else {
         size_t off = 0;
@@ -1450,6 +1453,7 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
         IpProf ps(h, "update", us);
         size_t off = 0;
         IpUpdArgs u{};
+        u.wt = h->wt;
         for (int t = 1; t <= L + 1; ++t) {
             u.W[t - 1] = h->W[t - 1]; u.wf[t - 1] = h->wf[t - 1]; u.wb[t - 1] = h->wb[t - 1]; u.off[t - 1] = off;
             u.Din[t - 1] = h->Dp[t - 1]; u.Dout[t - 1] = h->Dp[t]; u.sk[t - 1] = h->sk[t - 1];
@@ -1503,6 +1507,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_UPDATE_SIDE")) h->upd_side = atoi(e) != 0;
     if (const char* e = getenv("IPNN_IPF_NT")) h->ipf_nt = atoi(e) == 1024 ? 1024 : 512;
     if (const char* e = getenv("IPNN_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_WT")) h->wt = atoi(e) != 0;
     if (const char* e = getenv("IPNN_TAIL_NW")) h->tail_nw = atoi(e) == 16 ? 16 : 8;
     if (const char* e = getenv("IPNN_TAIL_NF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->tail_nf = v; }
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);

@@ -970,3 +970,30 @@ def test_train_epoch_equals_the_step_loop(built):
     assert not bad and np.array_equal(ta, tb), "step loop vs train_epoch differ: dense %r, table rows %r" % (
         bad, np.unique(np.argwhere(ta != tb)[:, 0])[:10].tolist())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode,prec", [('fm', 'bf16'), ('fm', 'f32'), ('fm', 'bf16x3'), ('bag', 'bf16')])
+def test_write_through_stores_change_no_bit(built, monkeypatch, mode, prec):
+    """The strip kernel's training outputs leave by write-through stores (gx' regrouped into whole lines), FNN_WT_STORES=0 keeps
+    plain stores: the same values either way, so 30 back-to-back steps (no host synchronisation between them) must leave the
+    table, the dense tensors and the bag bias bit-equal -- a store the next launch did not see in time would show here."""
+    steps, B = 30, 700
+    res = []
+    for wt in ('0', None):
+        if wt is None:
+            monkeypatch.delenv('FNN_WT_STORES', raising=False)
+        else:
+            monkeypatch.setenv('FNN_WT_STORES', wt)
+        if mode == 'fm':
+            rows, fo, ids, y, p, r1, r2 = make_problem(steps * B, seed=5, dup_col=6)
+            eng = make_engine(rows, fo, p, prec=prec, lr=0.01, lam1=0.001, lamfm=0.1)
+        else:
+            ww0, bb0, ids, y, p, r1, r2 = make_snn_problem(steps * B, seed=6, dup_col=4)
+            eng = make_snn_engine(ww0, bb0, p, prec=prec)
+        for s in range(steps):
+            eng.train_step(ids[s * B:(s + 1) * B], y[s * B:(s + 1) * B], r1, r2, want_loss=False)
+        d = eng.get_dense()
+        res.append([eng.get_table()] + [np.asarray(d[k]) for k in sorted(d)] + ([eng.get_bag_bias()] if mode == 'bag' else []))
+        eng.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
