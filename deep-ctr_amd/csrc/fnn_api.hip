@@ -47,7 +47,7 @@ struct fnn_handle {
     int scat2_wgs = 256;        // workgroups walking the multi-chunk segments in launch 3
     bool bf16 = false;          // FNN_PREC_BF16: 2-byte elements
     bool split = false;         // FNN_PREC_BF16X3: 4-byte elements (bs16_t), the f32 mode's layouts
-    int wt_stores = 7;                                                 // FNN_WT_STORES (MlpArgs::wt; 0: plain stores): how the strip kernel's training outputs leave
+    int wt_stores = 15;                                                // FNN_WT_STORES (MlpArgs::wt; 0: plain stores): how the strip kernel's training outputs leave
     bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
     float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
     bool fused = true;          // one k_mlp launch instead of gather/fwd1/fwd2/head/bwd1/gx
@@ -1136,10 +1136,10 @@ int fnn_gather(fnn_handle* h, const int32_t* ids, int B, float* x_out, int memki
             ProfScope ps(h, "gather_ref", h->st);
             if (h->bag)
                 hipLaunchKernelGGL(k_bag_ref, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, h->st, ids_dev, nb, h->F,
-                                   h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag);
+                                   h->rw, h->table16, h->n_rows, h->bb0, x_dev, h->err_flag, (h->wt_stores & 16) != 0);   // (measured: 1 % slower written through -- off)
             else
                 hipLaunchKernelGGL(k_gather_ref, dim3((unsigned)((nb + GR_EX - 1) / GR_EX)), dim3(256), (size_t)GR_EX * (h->xdim + h->F) * sizeof(float), h->st, ids_dev, nb, h->F,
-                                   h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag);
+                                   h->K, h->table16, h->n_rows, h->w0, x_dev, h->err_flag, (h->wt_stores & 8) != 0);
         }
         if (host) {
             HIPCHK(h, hipMemcpyAsync(x_out + (size_t)lo * h->xdim, x_dev, n * 4, hipMemcpyDeviceToHost, h->st));

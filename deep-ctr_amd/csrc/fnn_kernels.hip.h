@@ -342,7 +342,7 @@ static __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict
 constexpr int GR_EX = 16;
 static __global__ __launch_bounds__(256) void k_gather_ref(const int32_t* __restrict__ ids, int B, int F, int K,
                              const float* __restrict__ table16, int64_t n_rows, float w0,
-                             float* __restrict__ x, int* __restrict__ err)
+                             float* __restrict__ x, int* __restrict__ err, const bool wt)
 {
     extern __shared__ __align__(16) unsigned char gr_smem[];
     float* sx = reinterpret_cast<float*>(gr_smem);                  // [GR_EX][xdim]
@@ -376,7 +376,7 @@ static __global__ __launch_bounds__(256) void k_gather_ref(const int32_t* __rest
     const int nex = min(GR_EX, B - t0);
     const size_t base = (size_t)t0 * xdim;                          // multiple of 16 floats: 16-byte aligned
     const int nfl = nex * xdim, n4 = nfl >> 2;
-    for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(x + base)[i] = reinterpret_cast<const float4*>(sx)[i];
+    for (int i = threadIdx.x; i < n4; i += 256) store16_sel(wt, reinterpret_cast<float4*>(x + base) + i, reinterpret_cast<const float4*>(sx)[i]);   // (written through: the output is the caller's)
     for (int i = 4 * n4 + threadIdx.x; i < nfl; i += 256) x[base + i] = sx[i];
 }
 
@@ -911,6 +911,7 @@ template <typename T> struct MlpArgs {
     // embedding-bag input layer (SNN fine-tune, python/SNN_RBM.py:238-291); unused in FM mode
     const float* bb0; int rw; T* dlxT; float* gx_raw;
     int wt;                         // bits: 1 the transposed activations by write-through stores (store4_wt), 2 gx' too, 4 gx' regrouped into whole lines
+                                    // (bit 8 of FNN_WT_STORES: the reference-shaped outputs of fnn_gather, k_gather_ref / k_bag_ref)
 #ifdef FNN_STAMPS
     long long* dbg;                 // diagnostic build only: per-workgroup phase time stamps
 #endif
@@ -1900,7 +1901,7 @@ __device__ __forceinline__ void scatw2_body(const ScatArgs& sa, const int blk, c
 // L1 broadcast); consecutive threads read consecutive pieces of the same 800-byte rows.
 static __global__ __launch_bounds__(256) void k_bag_ref(const int32_t* __restrict__ ids, int B, int F, int rw,
                                                          const float* __restrict__ table, int64_t n_rows,
-                                                         const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err)
+                                                         const float* __restrict__ bb0, float* __restrict__ x, int* __restrict__ err, const bool wt)
 {
     const int nq = rw >> 2;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1921,8 +1922,8 @@ static __global__ __launch_bounds__(256) void k_bag_ref(const int32_t* __restric
 #pragma unroll
         for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    *reinterpret_cast<float4*>(x + (size_t)t * rw + 4 * c4) =
-        make_float4(1.0f / (1.0f + expf(-acc.x)), 1.0f / (1.0f + expf(-acc.y)), 1.0f / (1.0f + expf(-acc.z)), 1.0f / (1.0f + expf(-acc.w)));
+    store16_sel(wt, x + (size_t)t * rw + 4 * c4,
+                make_float4(1.0f / (1.0f + expf(-acc.x)), 1.0f / (1.0f + expf(-acc.y)), 1.0f / (1.0f + expf(-acc.z)), 1.0f / (1.0f + expf(-acc.w))));
 }
 static __global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, float a, int n)
 {
