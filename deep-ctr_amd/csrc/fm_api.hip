@@ -24,6 +24,7 @@ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 struct FmArgs {
     const int32_t* ids; const float* y; int B, F, K; const float* table16; int64_t n_rows; const float* b;
     float scale, dscale; int train; float* gxp; int K1p; float* p_out; float* loss_t; float* gb_part; int* err;
+    bool wt;                   // gx' written through (see store4_wt in fnn_kernels.hip.h)
 };
 
 __device__ __forceinline__ void fm_body(const FmArgs& a, const int blk, float* s_gb)
@@ -75,7 +76,7 @@ __device__ __forceinline__ void fm_body(const FmArgs& a, const int blk, float* s
     float* out = a.gxp + (size_t)t * a.K1p + f * SLOT;
     if (f < a.F) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(out + 4 * q) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) store16_sel(a.wt, out + 4 * q, make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]));   // (written through: FM_WT=0 for plain stores)
     }
     if (f == 0) s_gb[grp] = delta;
     __syncthreads();
@@ -157,7 +158,7 @@ int fm_run(fm_handle* h, const int32_t* ids, const float* y, int B, float lr, fl
 {
     const int Ba = rup(B, 16), F = h->F;
     FmArgs a{ids, y, B, F, h->K, h->table16, h->n_rows, h->b, (float)h->scale, reduce_mean ? 1.0f / (float)B : 1.0f, train ? 1 : 0,
-             h->gxp, h->K1p, p_out, h->loss_t, h->gb_part, h->err_flag};
+             h->gxp, h->K1p, p_out, h->loss_t, h->gb_part, h->err_flag, !(getenv("FM_WT") && atoi(getenv("FM_WT")) == 0)};
     if (!train) {
         hipLaunchKernelGGL(k_fm, dim3(Ba / 16), dim3(256), 0, h->st, a);
         MHK(h, hipGetLastError());
