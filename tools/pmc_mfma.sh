@@ -20,7 +20,9 @@ for (name, grid), c in acc.items():
     act = sum(c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE'])
     mops = sum(c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', [0])) / max(1, len(c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', [0])))
     out['%s grid %s' % (name, grid)] = {'launches': len(c['GRBM_GUI_ACTIVE']), 'mfma_busy_cycles': busy, 'gui_active_cycles': act,
-                                       'mfma_util_pct': 100.0 * busy / (act * 1024.0), 'bf16_mfma_flops': mops * 512}
+                                       'mfma_util_pct': 100.0 * busy / (act * 1024.0),
+                                       # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs: the fraction of SIMD cycles with an MFMA in flight is 8 x the above
+                                       'mfma_util_pct_xcd_normalised': 100.0 * busy / (act / 8.0 * 1024.0), 'bf16_mfma_flops': mops * 512}
 print(json.dumps(out, indent=1))
 PY
 cat gpurun_out/pmc_mfma_$W.json
