@@ -47,6 +47,7 @@ struct fnn_handle {
     int scat2_wgs = 256;        // workgroups walking the multi-chunk segments in launch 3
     bool bf16 = false;          // FNN_PREC_BF16: 2-byte elements
     bool split = false;         // FNN_PREC_BF16X3: 4-byte elements (bs16_t), the f32 mode's layouts
+    int step1_waves = 8;                                               // FNN_STEP1_WAVES=4: four waves per strip (the 2-byte element types at hidden 300 / 100 run eight)
     int wt_stores = 15;                                                // FNN_WT_STORES (MlpArgs::wt; 0: plain stores): how the strip kernel's training outputs leave
     bool bag = false; int rw = SLOT; size_t nbag = 0, off_bag = 0;     // FNN_MODE_BAG: bag rows rw floats wide
     float* bb0 = nullptr; void* dlxT = nullptr; void* onesT = nullptr; float* gx_raw = nullptr;
@@ -236,17 +237,35 @@ template <typename T> MlpArgs<T> make_mlp_args(fnn_handle* h, const int32_t* ids
                       (T*)h->xpT, (T*)h->d1T, (T*)h->d2T, (T*)h->dl1T, (T*)h->dl2T, (T*)h->dl3T, h->ldT,
                       h->gxp, p_out, h->loss_t, h->err_flag, h->bb0, h->rw, (T*)h->dlxT, nullptr, h->wt_stores};
 }
-template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int F) {
+template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int F, int nw = 4) {
     constexpr int PAD = 16 / (int)sizeof(T);
     constexpr int LX = 64 * CX + PAD, L1 = 64 * C1 + PAD, L2 = 64 * C2 + PAD, LXM = LX > L1 ? LX : L1;
-    size_t n = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + 64 * sizeof(float);
+    size_t n = (size_t)16 * (LXM + L1 + L2) * sizeof(T) + (size_t)16 * nw * sizeof(float);
     if (bag) n += (size_t)16 * 64 * CX * sizeof(float) + (size_t)16 * F * sizeof(int);
-    else n += (size_t)4 * 16 * 36 * sizeof(float);            // the waves' blocks for regrouping gx' into whole lines (mlp_body, P4)
+    else n += (size_t)nw * 16 * 36 * sizeof(float);           // the waves' blocks for regrouping gx' into whole lines (mlp_body, P4)
     return n;
 }
 template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
     const bool big = h->H1p / 64 == 5;
     const dim3 g(nmlp), b(256);
+    if constexpr (sizeof(T) == 2) {
+        // the 2-byte element types at hidden 300 / 100: EIGHT waves per strip (two per SIMD), a layer's 16-column fragments in runs of
+        // ceil(n / 8) per wave -- the strip is a chain of phases, each as long as its busiest wave's run (FNN_STEP1_WAVES=4: four waves)
+        if (big && h->step1_waves == 8) {
+            const dim3 b8(512);
+            if (h->K1p / 64 == 5) {
+                const size_t lds = mlp_lds_bytes<T, 5, 2, 5>(true, h->F, 8);
+                hipLaunchKernelGGL((k_step1<T, 5, 2, 5, true, 8>), g, b8, lds, h->st, a);
+            } else if (h->bag) {
+                const size_t lds = mlp_lds_bytes<T, 5, 2, 4>(true, h->F, 8);
+                hipLaunchKernelGGL((k_step1<T, 5, 2, 4, true, 8>), g, b8, lds, h->st, a);
+            } else {
+                const size_t lds = mlp_lds_bytes<T, 5, 2, 4>(false, h->F, 8);
+                hipLaunchKernelGGL((k_step1<T, 5, 2, 4, false, 8>), g, b8, lds, h->st, a);
+            }
+            return;
+        }
+    }
     if (h->K1p / 64 == 5) {                                      // bag mode only (mlp_shape_ok)
         const size_t lds5 = mlp_lds_bytes<T, 5, 2, 5>(true, h->F);
         hipLaunchKernelGGL((k_step1<T, 5, 2, 5, true>), g, b, lds5, h->st, a);
@@ -805,6 +824,7 @@ int fnn_create(const fnn_cfg* cfg, fnn_handle** out)
     h->K1p = rup(h->F * SLOT, 64); h->H1p = rup(h->H1 + 1, 64); h->H2p = rup(h->H2 + 1, 64);
     h->bag = cfg->mode == FNN_MODE_BAG;
     if (const char* e = getenv("FNN_WT_STORES")) h->wt_stores = atoi(e);
+    if (const char* e = getenv("FNN_STEP1_WAVES")) h->step1_waves = atoi(e) == 4 ? 4 : 8;
     if (h->bag) { h->rw = cfg->h0; h->K = cfg->h0; h->xdim = cfg->h0; h->K1p = rup(cfg->h0 + 1, 64); }
     h->Bmax = cfg->max_batch; h->ldT = rup(h->Bmax, 256);
     h->N2max = SORT_N; while (h->N2max < h->Bmax) h->N2max <<= 1;    // the three-launch path groups SORT_N slots per field whatever max_batch is

@@ -981,20 +981,24 @@ __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r
 // BAG = true : layer one is x = sigmoid(sum of the F gathered rows of ww0 + bb0), rw floats wide
 //              (SNN, python/SNN_RBM.py:248-256), and the kernel returns
 //              delta = gx * x * (1 - x) (:288-290) instead of gx.
-template <typename T, int C1, int C2, int CX, bool BAG = false>
+// D1, D2, DX: 64-column blocks of H1p, H2p, K1p.  NW waves share a layer's 16-column fragments in contiguous runs of
+// C = ceil(fragments / NW) per wave (NW = 4: the blocks' own quarters, C = D; NW = 8: the last waves' runs are clipped -- `ok`).
+template <typename T, int D1, int D2, int DX, bool BAG = false, int NW = 4>
 __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, unsigned char* smem)
 {
+    constexpr int NF1 = 4 * D1, NF2 = 4 * D2, NFX = 4 * DX, NT = 64 * NW;
+    constexpr int C1 = (NF1 + NW - 1) / NW, C2 = (NF2 + NW - 1) / NW, CX = (NFX + NW - 1) / NW;
     typedef typename Traits<T>::frag frag;
     constexpr int EPL = Traits<T>::EPL, KS = Traits<T>::KS;
-    constexpr int K1p = 64 * CX, H1p = 64 * C1, H2p = 64 * C2;
+    constexpr int K1p = 64 * DX, H1p = 64 * D1, H2p = 64 * D2;
     constexpr int PAD = 16 / (int)sizeof(T);
     constexpr int LX = K1p + PAD, L1 = H1p + PAD, L2 = H2p + PAD;
     constexpr int LXM = LX > L1 ? LX : L1;
     T* sx = reinterpret_cast<T*>(smem);          // [16][LXM]  x' tile, later delta1 (stride L1)
     T* sd1 = sx + 16 * LXM;                      // [16][L1]   d1
     T* sdl2 = sd1 + 16 * L1;                     // [16][L2]   delta2
-    float* sz = reinterpret_cast<float*>(sdl2 + 16 * L2);   // [4][16]
-    float* sxf = sz + 64;                        // BAG: [16][K1p] f32 copy of x for delta
+    float* sz = reinterpret_cast<float*>(sdl2 + 16 * L2);   // [NW][16]
+    float* sxf = sz + 16 * NW;                   // BAG: [16][K1p] f32 copy of x for delta
     int* sids = reinterpret_cast<int*>(sxf + 16 * K1p);     // BAG: [16][F] ids of the strip
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -1018,7 +1022,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         const int col = (wave * C2 + i) * 16 + lr;
         const float mv = (float)a.m2[col < a.H2 ? col : 0];
         m2v[i] = (col < a.H2) ? mv : 0.0f;
-        w3v[i] = a.w3p[col];
+        w3v[i] = (wave * C2 + i < NF2) ? a.w3p[col] : 0.0f;
     }
 
     float rv[4];                                   // 1 for rows of the batch, 0 for the padding rows
@@ -1032,6 +1036,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     // (they do not depend on the activations), so the L2 latency of the weight stream hides under
     // the previous phase instead of being paid 8 loads at a time inside the MFMA loop.
     constexpr bool PF = sizeof(T) == 2;
+    static_assert(PF || NW == 4, "the register-ring weight stream (4-byte element types) assumes four waves: no clipped runs");
     constexpr int NK1 = K1p / KS, NKH1 = H1p / KS, NKH2 = H2p / KS;
     frag b1[PF ? NK1 : 1][PF ? C1 : 1];
     constexpr int DR1 = wring_depth<C1>(NK1), DR2 = wring_depth<C2>(NKH1), DR3 = wring_depth<C1>(NKH2), DR4 = wring_depth<CX>(NKH1);
@@ -1041,7 +1046,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int kk = 0; kk < NK1; ++kk)
 #pragma unroll
             for (int i = 0; i < C1; ++i)
-                b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, wave * C1 + i, kk, NK1, lane));
+                b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, min(wave * C1 + i, NF1 - 1), kk, NK1, lane));
     } else wring_head<T, NK1, C1, DR1>(r1, a.w1t, wave * C1, lane);
 
     if constexpr (BAG) {
@@ -1050,7 +1055,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         // loads in flight per item, rw/4 items per example.
         constexpr int BAGL = 16;             // row loads in flight per item (all 16 fields of an example at once)
         const int rw = a.rw, nq = rw >> 2;
-        for (int e = tid; e < 16 * F; e += 256) {
+        for (int e = tid; e < 16 * F; e += NT) {
             const int t = t0 + e / F;
             int id = -1;
             if (t < B) {
@@ -1060,7 +1065,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             sids[e] = id;
         }
         lds_barrier();
-        for (int e = tid; e < 16 * nq; e += 256) {
+        for (int e = tid; e < 16 * nq; e += NT) {
             const int r = e / nq, c4 = e % nq;
             float4 acc = *reinterpret_cast<const float4*>(a.bb0 + 4 * c4);
             for (int f0 = 0; f0 < F; f0 += BAGL) {
@@ -1083,14 +1088,14 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             store4(sx + r * LX + 4 * c4, x0, x1, x2, x3);
             *reinterpret_cast<float4*>(sxf + r * K1p + 4 * c4) = make_float4(x0, x1, x2, x3);
         }
-        for (int e = tid; e < 16 * (K1p - rw); e += 256) {       // ones column (b1 row) + padding
+        for (int e = tid; e < 16 * (K1p - rw); e += NT) {       // ones column (b1 row) + padding
             const int r = e / (K1p - rw), c = rw + e % (K1p - rw);
             const float v = (c == rw && t0 + r < B) ? 1.0f : 0.0f;
             sx[r * LX + c] = (T)v; sxf[r * K1p + c] = 0.0f;
         }
         lds_barrier();
         if (a.train) {
-            for (int e = tid; e < K1p * 4; e += 256) {
+            for (int e = tid; e < K1p * 4; e += NT) {
                 const int c = e >> 2, tq = e & 3;
                 ST4(a.xpT + ft_off<T>(c, t0 + 4 * tq, ldT), (float)sx[(4 * tq) * LX + c], (float)sx[(4 * tq + 1) * LX + c],
                     (float)sx[(4 * tq + 2) * LX + c], (float)sx[(4 * tq + 3) * LX + c]);
@@ -1099,7 +1104,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     } else {
     // ---- P0: gather 16 examples x F rows (64 B each) into the x' tile and x'^T (:87-96).
     // All ids first, then all rows: two dependent round trips for the whole strip.
-    for (int e = tid; e < 16 * F; e += 256) {
+    for (int e = tid; e < 16 * F; e += NT) {
         const int q = e & 3, f = (e >> 2) % F, tq = (e >> 2) / F;
         int64_t id[4];
 #pragma unroll
@@ -1138,7 +1143,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 ST4(a.xpT + ft_off<T>(c0 + j, t0 + 4 * tq, ldT), v[0][j], v[1][j], v[2][j], v[3][j]);
         }
     }
-    for (int e = tid; e < 16 * (K1p - F * SLOT); e += 256) {       // pad columns of the tile
+    for (int e = tid; e < 16 * (K1p - F * SLOT); e += NT) {       // pad columns of the tile
         const int r = e / (K1p - F * SLOT), c = F * SLOT + e % (K1p - F * SLOT);
         sx[r * LX + c] = (T)0.f;
     }
@@ -1155,7 +1160,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int kk = 0; kk < NKH1; ++kk)
 #pragma unroll
             for (int i = 0; i < C2; ++i)
-                b2[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, wave * C2 + i, kk, NKH1, lane));
+                b2[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, min(wave * C2 + i, NF2 - 1), kk, NKH1, lane));
     } else wring_head<T, NKH1, C2, DR2>(r2, a.w2t, wave * C2, lane);
     {
         f32x4 acc[C1];
@@ -1176,18 +1181,19 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
+            const bool ok = wave * C1 + i < NF1;
             const float m = m1v[i], one = (col == a.H1) ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = fmaf(act_apply(ac1, acc[i][r]), m, one) * rv[r];
                 d1v[i][r] = v;
-                sd1[(4 * lq + r) * L1 + col] = (T)v;
+                if (ok) sd1[(4 * lq + r) * L1 + col] = (T)v;
             }
         }
         if (a.train) {
 #pragma unroll
             for (int i = 0; i < C1; ++i)
-                ST4(a.d1T + ft_off<T>((wave * C1 + i) * 16 + lr, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
+                if (wave * C1 + i < NF1) ST4(a.d1T + ft_off<T>((wave * C1 + i) * 16 + lr, t0 + 4 * lq, ldT), d1v[i][0], d1v[i][1], d1v[i][2], d1v[i][3]);
         }
     }
     lds_barrier();
@@ -1203,7 +1209,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
             for (int kk = 0; kk < NKH2; ++kk)
 #pragma unroll
                 for (int i = 0; i < C1; ++i)
-                    b3[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, wave * C1 + i, kk, NKH2, lane));
+                    b3[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, min(wave * C1 + i, NF1 - 1), kk, NKH2, lane));
         }
     } else { if (a.train) wring_head<T, NKH2, C1, DR3>(r3, a.w2, wave * C1, lane); }
     {
@@ -1235,7 +1241,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         if (a.train) {
 #pragma unroll
             for (int i = 0; i < C2; ++i)
-                ST4(a.d2T + ft_off<T>((wave * C2 + i) * 16 + lr, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
+                if (wave * C2 + i < NF2) ST4(a.d2T + ft_off<T>((wave * C2 + i) * 16 + lr, t0 + 4 * lq, ldT), d2v[i][0], d2v[i][1], d2v[i][2], d2v[i][3]);
         }
     }
 #pragma unroll
@@ -1249,7 +1255,10 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r, t = t0 + row;
-        zr[r] = sz[row] + sz[16 + row] + sz[32 + row] + sz[48 + row];
+        float zs = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) zs += sz[16 * w + row];
+        zr[r] = zs;
         const float p = sigmoid_fast(zr[r]);
         d3[r] = (a.train && t < B) ? p - yv[r] : 0.f;
         if (a.p_out && wave == 0 && lr == 0 && t < B) a.p_out[t] = p;
@@ -1270,6 +1279,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
     for (int i = 0; i < C2; ++i) {
         const int col = (wave * C2 + i) * 16 + lr;
+        if (wave * C2 + i >= NF2) continue;
         const float w3m = w3v[i] * m2v[i];
         float v[4];
 #pragma unroll
@@ -1291,7 +1301,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
         for (int kk = 0; kk < NKH1; ++kk)
 #pragma unroll
             for (int i = 0; i < CX; ++i)
-                b4[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, wave * CX + i, kk, NKH1, lane));
+                b4[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, min(wave * CX + i, NFX - 1), kk, NKH1, lane));
     } else wring_head<T, NKH1, CX, DR4>(r4, a.w1, wave * CX, lane);
     {
         f32x4 acc[C1];
@@ -1311,6 +1321,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
             const int col = (wave * C1 + i) * 16 + lr;
+            if (wave * C1 + i >= NF1) continue;
             const float m = m1v[i];
             float v[4];
 #pragma unroll
@@ -1344,7 +1355,8 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 // gx' [example][K1p] f32 in whole 128-byte lines: two fragments (32 columns) at a time through a wave-private LDS
                 // block -- the MFMA layout has a lane on 4 ROWS of one column (sixteen 4-byte stores per lane,
                 // 64-byte pieces per instruction); regrouped, a lane holds 4 columns of one row (four 16-byte stores per lane)
-                float* sg = sz + 64 + wave * (16 * 36);           // behind the tiles (mlp_lds_bytes: FM mode keeps 4 x 2,304 bytes there)
+                static_assert(NFX % NW == 0, "gx' regrouping: whole runs");
+                float* sg = sz + 16 * NW + wave * (16 * 36);           // behind the tiles (mlp_lds_bytes: FM mode keeps 4 x 2,304 bytes there)
 #pragma unroll
                 for (int ip = 0; ip < CX / 2; ++ip) {
 #pragma unroll
@@ -1367,6 +1379,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
         for (int i = 0; i < CX; ++i) {
             const int col = (wave * CX + i) * 16 + lr;
+            if (wave * CX + i >= NFX) continue;
             if constexpr (BAG) {       // delta = gx * x * (1 - x)  (python/SNN_RBM.py:288-290, lr applied later)
                 float v[4];
 #pragma unroll

@@ -178,11 +178,11 @@ static __global__ __launch_bounds__(256) void k_sortB(const SortArgs so)
 // step 1: MLP strips of this batch.  (At 256 VGPRs a strip workgroup fills its CU, so the sort
 // roles ride on steps 2 and 3, whose workgroups are small enough to share a CU.)
 // ------------------------------------------------------------------------------------------
-template <typename T, int C1, int C2, int CX, bool BAG>
-static __global__ __launch_bounds__(256) void k_step1(const MlpArgs<T> a)
+template <typename T, int C1, int C2, int CX, bool BAG, int NW = 4>
+static __global__ __launch_bounds__(64 * NW) void k_step1(const MlpArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    mlp_body<T, C1, C2, CX, BAG>(a, blockIdx.x, smem);
+    mlp_body<T, C1, C2, CX, BAG, NW>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
