@@ -248,8 +248,8 @@ template <typename T, int C1, int C2, int CX> size_t mlp_lds_bytes(bool bag, int
 template <typename T> void launch_step1(fnn_handle* h, int nmlp, const MlpArgs<T>& a) {
     const bool big = h->H1p / 64 == 5;
     const dim3 g(nmlp), b(256);
-    if constexpr (sizeof(T) == 2) {
-        // the 2-byte element types at hidden 300 / 100: EIGHT waves per strip (two per SIMD), a layer's 16-column fragments in runs of
+    {
+        // hidden 300 / 100: EIGHT waves per strip (two per SIMD), a layer's 16-column fragments in runs of
         // ceil(n / 8) per wave -- the strip is a chain of phases, each as long as its busiest wave's run (FNN_STEP1_WAVES=4: four waves)
         if (big && h->step1_waves == 8) {
             const dim3 b8(512);

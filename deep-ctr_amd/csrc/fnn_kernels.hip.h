@@ -934,16 +934,17 @@ template <typename T, int C, int D> struct WRing { typename Traits<T>::frag s[D]
 #define FNN_WRING_FRAGS 30            // fragments of a ring: D = FNN_WRING_FRAGS / C k-steps in flight
 #endif
 template <int C> constexpr int wring_depth(int nk) { return (FNN_WRING_FRAGS / C) < nk ? (FNN_WRING_FRAGS / C) : nk; }
+// (rtmax: the operand's last row tile -- a wave whose run of C fragments is clipped re-reads that one, its products are discarded)
 template <typename T, int NK, int C, int D>
-__device__ __forceinline__ void wring_head(WRing<T, C, D>& r, const T* __restrict__ W, const int rt0, const int lane) {
+__device__ __forceinline__ void wring_head(WRing<T, C, D>& r, const T* __restrict__ W, const int rt0, const int lane, const int rtmax) {
     typedef typename Traits<T>::frag frag;
 #pragma unroll
     for (int kk = 0; kk < D; ++kk)
 #pragma unroll
-        for (int i = 0; i < C; ++i) r.s[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk, NK, lane));
+        for (int i = 0; i < C; ++i) r.s[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, min(rt0 + i, rtmax), kk, NK, lane));
 }
 template <typename T, int NK, int C, int D>
-__device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r, const T* ap, const T* __restrict__ W, const int rt0, const int lane) {
+__device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r, const T* ap, const T* __restrict__ W, const int rt0, const int lane, const int rtmax) {
     typedef typename Traits<T>::frag frag;
     constexpr int KS = Traits<T>::KS;
 #ifndef FNN_SPLIT_PAIRED
@@ -958,7 +959,7 @@ __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r
             for (int u = 0; u < 2; ++u)
                 if (kk + u + D < NK) {
 #pragma unroll
-                    for (int i = 0; i < C; ++i) r.s[(kk + u) % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + u + D, NK, lane));
+                    for (int i = 0; i < C; ++i) r.s[(kk + u) % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, min(rt0 + i, rtmax), kk + u + D, NK, lane));
                 }
         }
         if (NK & 1) {
@@ -972,7 +973,7 @@ __device__ __forceinline__ void wring_product(f32x4 (&acc)[C], WRing<T, C, D>& r
         mma_row<C>(acc, af, r.s[kk % D]);
         if (kk + D < NK) {
 #pragma unroll
-            for (int i = 0; i < C; ++i) r.s[kk % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, rt0 + i, kk + D, NK, lane));
+            for (int i = 0; i < C; ++i) r.s[kk % D][i] = *reinterpret_cast<const frag*>(ft_frag<T>(W, min(rt0 + i, rtmax), kk + D, NK, lane));
         }
     }
     }
@@ -1036,7 +1037,6 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
     // (they do not depend on the activations), so the L2 latency of the weight stream hides under
     // the previous phase instead of being paid 8 loads at a time inside the MFMA loop.
     constexpr bool PF = sizeof(T) == 2;
-    static_assert(PF || NW == 4, "the register-ring weight stream (4-byte element types) assumes four waves: no clipped runs");
     constexpr int NK1 = K1p / KS, NKH1 = H1p / KS, NKH2 = H2p / KS;
     frag b1[PF ? NK1 : 1][PF ? C1 : 1];
     constexpr int DR1 = wring_depth<C1>(NK1), DR2 = wring_depth<C2>(NKH1), DR3 = wring_depth<C1>(NKH2), DR4 = wring_depth<CX>(NKH1);
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
             for (int i = 0; i < C1; ++i)
                 b1[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1t, min(wave * C1 + i, NF1 - 1), kk, NK1, lane));
-    } else wring_head<T, NK1, C1, DR1>(r1, a.w1t, wave * C1, lane);
+    } else wring_head<T, NK1, C1, DR1>(r1, a.w1t, wave * C1, lane, NF1 - 1);
 
     if constexpr (BAG) {
         // ---- P0 (bag): x = sigmoid(sum_f ww0[id_f] + bb0).  ids of the strip first (one per thread),
@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
             for (int i = 0; i < C2; ++i)
                 b2[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2t, min(wave * C2 + i, NF2 - 1), kk, NKH1, lane));
-    } else wring_head<T, NKH1, C2, DR2>(r2, a.w2t, wave * C2, lane);
+    } else wring_head<T, NKH1, C2, DR2>(r2, a.w2t, wave * C2, lane, NF2 - 1);
     {
         f32x4 acc[C1];
 #pragma unroll
@@ -1174,7 +1174,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
                 for (int i = 0; i < C1; ++i) mma(acc[i], af, b1[kk][i]);
             }
-        } else wring_product<T, NK1, C1, DR1>(acc, r1, ap, a.w1t, wave * C1, lane);
+        } else wring_product<T, NK1, C1, DR1>(acc, r1, ap, a.w1t, wave * C1, lane, NF1 - 1);
         FNN_STAMP(2);
         // m1v is 0 outside the real columns, so act(z)*m + [col == H1] is the ones column / padding too
         const ActCoef ac1 = act_coef(a.act1);
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
                 for (int i = 0; i < C1; ++i)
                     b3[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w2, min(wave * C1 + i, NF1 - 1), kk, NKH2, lane));
         }
-    } else { if (a.train) wring_head<T, NKH2, C1, DR3>(r3, a.w2, wave * C1, lane); }
+    } else { if (a.train) wring_head<T, NKH2, C1, DR3>(r3, a.w2, wave * C1, lane, NF1 - 1); }
     {
         f32x4 acc[C2];
 #pragma unroll
@@ -1224,7 +1224,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
                 for (int i = 0; i < C2; ++i) mma(acc[i], af, b2[kk][i]);
             }
-        } else wring_product<T, NKH1, C2, DR2>(acc, r2, ap, a.w2t, wave * C2, lane);
+        } else wring_product<T, NKH1, C2, DR2>(acc, r2, ap, a.w2t, wave * C2, lane, NF2 - 1);
         FNN_STAMP(4);
         const ActCoef ac2 = act_coef(a.act2);
 #pragma unroll
@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
             for (int i = 0; i < CX; ++i)
                 b4[kk][i] = *reinterpret_cast<const frag*>(ft_frag<T>(a.w1, min(wave * CX + i, NFX - 1), kk, NKH1, lane));
-    } else wring_head<T, NKH1, CX, DR4>(r4, a.w1, wave * CX, lane);
+    } else wring_head<T, NKH1, CX, DR4>(r4, a.w1, wave * CX, lane, NFX - 1);
     {
         f32x4 acc[C1];
 #pragma unroll
@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
                 for (int i = 0; i < C1; ++i) mma(acc[i], af, b3[kk][i]);
             }
-        } else wring_product<T, NKH2, C1, DR3>(acc, r3, ap, a.w2, wave * C1, lane);
+        } else wring_product<T, NKH2, C1, DR3>(acc, r3, ap, a.w2, wave * C1, lane, NF1 - 1);
         FNN_STAMP(7);
         const ActCoef ac1 = act_coef(a.act1);
 #pragma unroll
@@ -1348,17 +1348,17 @@ __device__ __forceinline__ void mlp_body(const MlpArgs<T>& a, const int blk, uns
 #pragma unroll
                 for (int i = 0; i < CX; ++i) mma(acc[i], af, b4[kk][i]);
             }
-        } else wring_product<T, NKH1, CX, DR4>(acc, r4, ap, a.w1, wave * CX, lane);
+        } else wring_product<T, NKH1, CX, DR4>(acc, r4, ap, a.w1, wave * CX, lane, NFX - 1);
         FNN_STAMP(9);
         if constexpr (!BAG && CX % 2 == 0) {
             if (a.wt & 4) {
                 // gx' [example][K1p] f32 in whole 128-byte lines: two fragments (32 columns) at a time through a wave-private LDS
                 // block -- the MFMA layout has a lane on 4 ROWS of one column (sixteen 4-byte stores per lane,
                 // 64-byte pieces per instruction); regrouped, a lane holds 4 columns of one row (four 16-byte stores per lane)
-                static_assert(NFX % NW == 0, "gx' regrouping: whole runs");
                 float* sg = sz + 16 * NW + wave * (16 * 36);           // behind the tiles (mlp_lds_bytes: FM mode keeps 4 x 2,304 bytes there)
 #pragma unroll
                 for (int ip = 0; ip < CX / 2; ++ip) {
+                    if (wave * CX + 2 * ip >= NFX) break;                 // a clipped run (CX is even: pairs never straddle the end)
 #pragma unroll
                     for (int f = 0; f < 2; ++f)
 #pragma unroll
