@@ -896,7 +896,7 @@ static __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) { wgrad
 // workgroup, in ONE launch (python/FNN_wnzh.py:144-174 + :87-96).  The six products that the
 // reference's Theano graph runs one after another (x.w1, d1.w2, d2.w3, delta2.w2^T, delta1.w1^T)
 // never leave the CU: the strip's activations live in LDS (padded rows, conflict-free
-// ds_read_b128 fragments), each of the 4 waves owns a quarter of every layer's output columns,
+// ds_read_b128 fragments), each of the workgroup's waves (8; 4 with FNN_STEP1_WAVES=4) owns a contiguous run of every layer's output fragments,
 // and the weights stream from L2 straight into B fragments.  What goes back to HBM is only what
 // later kernels need: the transposed activations for the weight-gradient GEMMs, gx' for the
 // sparse-row update, p / loss.  Dimensions are compile-time: K1p = 64*CX, H1p = 64*C1,
