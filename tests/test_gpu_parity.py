@@ -120,6 +120,16 @@ def test_train_step_f32_vs_oracle(built, B, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("B,kw", [(5, {"empty": [(2, 3), (4, 0)]}), (257, {"dup_col": 0}), (1000, {"empty": [(0, 15)]})])
+def test_train_step_f32_vs_oracle_four_waves(built, monkeypatch, B, kw):
+    """The strip kernel's four-wave form (FNN_STEP1_WAVES=4; eight waves is the default since round 3) against the oracle."""
+    monkeypatch.setenv('FNN_STEP1_WAVES', '4')
+    rows, fo, ids, y, p, r1, r2 = make_problem(B, seed=B, **kw)
+    eng = make_engine(rows, fo, p, lr=0.01, lam1=0.02, lamfm=0.1)
+    _check_step(eng, rows, ids, y, p, r1, r2, 0.01, 0.02, 0.1)
+    eng.close()
+
+
 @pytest.mark.parametrize("prec", ['f32', 'bf16'])
 def test_layer_by_layer_path_matches_strip_kernel(built, prec, monkeypatch):
     """FNN_NO_FUSE=1 selects the layer-by-layer kernels (the path for shapes the fused strip
@@ -972,13 +982,16 @@ def test_train_epoch_equals_the_step_loop(built):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("waves", [None, '4'])
 @pytest.mark.parametrize("mode,prec", [('fm', 'bf16'), ('fm', 'f32'), ('fm', 'bf16x3'), ('bag', 'bf16')])
-def test_write_through_stores_change_no_bit(built, monkeypatch, mode, prec):
+def test_write_through_stores_change_no_bit(built, monkeypatch, mode, prec, waves):
     """The strip kernel's training outputs leave by write-through stores (gx' regrouped into whole lines), FNN_WT_STORES=0 keeps
     plain stores: the same values either way, so 30 back-to-back steps (no host synchronisation between them) must leave the
     table, the dense tensors and the bag bias bit-equal -- a store the next launch did not see in time would show here."""
     steps, B = 30, 700
     res = []
+    if waves is not None:
+        monkeypatch.setenv('FNN_STEP1_WAVES', waves)          # the four-wave form of the strip kernel (eight is the default)
     for wt in ('0', None):
         if wt is None:
             monkeypatch.delenv('FNN_WT_STORES', raising=False)
