@@ -549,9 +549,10 @@ __device__ __forceinline__ bool duo_split(const StripDuo& d, const int nblk) { r
 __device__ __forceinline__ int duo_count(const bool split, const int nblk, const int h) { return split ? (nblk - h + 1) >> 1 : nblk; }
 // Workgroups walk their list in rotated order (list entry i of a workgroup with rotation g is entry (i + g) mod cnt), so
 // that the workgroups of an XCD do not all stream the same weights -- the same L2 channels -- at the same moment.
-__device__ __forceinline__ int strip_phys(const bool split, const int i, const int cnt, const int h, const int rot) {
-    const int r = (i + rot) % cnt;
-    return split ? 2 * r + h : r;
+// (per items per 64-column block: entry r of the list is sub-item r % per of the workgroup's own block r / per)
+__device__ __forceinline__ int strip_phys(const bool split, const int i, const int cnt, const int h, const int rot, const int per = 1) {
+    const int r = (i + rot) % cnt, ob = r / per;
+    return (split ? 2 * ob + h : ob) * per + r % per;
 }
 template <typename T> __device__ __forceinline__ bool strip_has_out(const StripFwdArgs<T>& a) { return a.has_out != 0; }
 template <typename T> __device__ __forceinline__ bool strip_has_out(const StripBwdArgs<T>&) { return false; }
@@ -582,17 +583,25 @@ typedef unsigned int duo_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t duo_rsrc(const StripDuo& d) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)d.xch, 0, (int)(d.xch_wg * 8 * (size_t)gridDim.x), 0x00020000);
 }
-template <typename T, int RT>
-__device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const int N, const int j, const int parity, const int lane)
-{   // by the wave that has just written block j of the tile `out` (LDS operations of one wave complete in order)
+template <typename T, int RT, int NF = 4>
+__device__ __forceinline__ void duo_push(const StripDuo& d, const T* out, const int N, const int item, const int parity, const int lane)
+{   // by the wave that has just written item `item` (NF fragments of block j = item NF / 4) of the tile `out` (LDS operations of one
+    // wave complete in order); a block's RT x 2 KB keep the order they have in the LDS tile, so an item's 16-byte pieces are a run of it
+    constexpr int PER = 4 / NF, PIECES = 16 * NF * (int)sizeof(T);       // 16-byte pieces per row tile: 128 (a block), 64, 32
+    const int j = item / PER, sub = item % PER;
     const __amdgpu_buffer_rsrc_t rs = duo_rsrc(d);
-    const size_t dst = ((size_t)blockIdx.x * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + (size_t)(j >> 1) * (RT * 256)) * 8;     // bytes
+    const size_t dst = ((size_t)blockIdx.x * d.xch_wg + (size_t)parity * (d.xch_wg >> 1) + (size_t)(j >> 1) * (RT * 256)) * 8 + (size_t)sub * PIECES * 16;     // bytes
 #pragma unroll
     for (int m = 0; m < RT; ++m) {
-        const duo_u32x4* src = reinterpret_cast<const duo_u32x4*>(out + ft_off<T>(m * 16, j * 64, N));
-        const duo_u32x4 v0 = src[lane], v1 = src[lane + 64];
-        __builtin_amdgcn_raw_buffer_store_b128(v0, rs, (int)(dst + m * 2048 + lane * 16), 0, 16);                // aux 16 = sc1: write-through
-        __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (int)(dst + m * 2048 + (lane + 64) * 16), 0, 16);
+        const duo_u32x4* src = reinterpret_cast<const duo_u32x4*>(out + ft_off<T>(m * 16, item * NF * 16, N));
+        if (PIECES >= 128) {
+            const duo_u32x4 v0 = src[lane], v1 = src[lane + 64];
+            __builtin_amdgcn_raw_buffer_store_b128(v0, rs, (int)(dst + m * 2048 + lane * 16), 0, 16);                // aux 16 = sc1: write-through
+            __builtin_amdgcn_raw_buffer_store_b128(v1, rs, (int)(dst + m * 2048 + (lane + 64) * 16), 0, 16);
+        } else if (lane < PIECES) {
+            const duo_u32x4 v0 = src[lane];
+            __builtin_amdgcn_raw_buffer_store_b128(v0, rs, (int)(dst + m * 2048 + lane * 16), 0, 16);
+        }
     }
 }
 // block j of the tile `out`, just written by this wave, to its place in an F-layout operand in HBM (plain 16-byte stores; the
@@ -618,7 +627,7 @@ __device__ __forceinline__ void strip_final_push(T* __restrict__ dstF, const T* 
 }
 // every wave has drained its pushes -> flag -> the partner's flag -> the partner's blocks into `out`.  `pull` = false: this
 // workgroup has nothing left to compute (it only publishes).  All 64 NW threads call it.
-template <typename T, int RT>
+template <typename T, int RT, int NW = STRIP_NW>
 __device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N, const int nblk, const int h, const int parity, const int seq,
                                          const bool pull, long long* dbg)
 {
@@ -643,18 +652,19 @@ __device__ __forceinline__ void duo_swap(const StripDuo& d, T* out, const int N,
     if (dbg && threadIdx.x == 0) { ta = (long long)__builtin_amdgcn_s_memtime(); dbg[12] += ta - tb; }    // flag + the partner's
     // a block = RT x 2 KB = RT x 128 pieces of 16 bytes: threads 0..255 take the partner's blocks 0, 2, ..., threads 256..511 the odd ones
     const int ph = h ^ 1, cntp = (nblk - ph + 1) >> 1, t = threadIdx.x, pc = t & 255, m = pc >> 7, idx = pc & 127;
+    constexpr int G = NW / 4;                                        // groups of 256 threads: group g takes the partner's blocks g, g + G, ...
     const __amdgpu_buffer_rsrc_t rs = duo_rsrc(d);
     const size_t src = ((size_t)(blockIdx.x ^ 1) * d.xch_wg + (size_t)parity * (d.xch_wg >> 1)) * 8 + (size_t)pc * 16;                 // bytes
-    for (int r0 = 0; r0 < cntp && m < RT; r0 += 8) {                 // four loads in flight per thread
+    for (int r0 = 0; r0 < cntp && m < RT; r0 += 4 * G) {             // four loads in flight per thread
         duo_u32x4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int r = r0 + (t >> 8) + 2 * k;
+            const int r = r0 + (t >> 8) + G * k;
             if (r < cntp) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(src + (size_t)r * (RT * 2048)), 0, 16);           // sc1: from L2
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int r = r0 + (t >> 8) + 2 * k;
+            const int r = r0 + (t >> 8) + G * k;
             if (r < cntp) reinterpret_cast<duo_u32x4*>(out + ft_off<T>(m * 16, (2 * r + ph) * 64, N))[idx] = v[k];
         }
     }
@@ -687,8 +697,8 @@ __device__ __forceinline__ void strip_fwd_body(const StripFwdArgs<T>& a, const i
             bool sp; int cn; blocks(nx.p, sp, cn);
             const int wo = RT == 1 ? a.wlds[nx.p] : -1;
             // (spelled from the LDS array itself: through the captured pointer the address space was lost and the loads came out flat_)
-            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
-            else strip_prefetch<T, NF>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot, PER), lane);
+            else strip_prefetch<T, NF>(pb, a.W[nx.p], a.Dp[nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot, PER), lane);
         }
     };
     if (RT == 1) {                                               // the small products' weights -> LDS (contiguous, fragment-tiled: offsets carry over)
@@ -712,7 +722,7 @@ __device__ __forceinline__ void strip_fwd_body(const StripFwdArgs<T>& a, const i
         const bool fin = !a.has_out && l + 1 == a.n;            // the launch stops here: blocks go to HBM, nobody swaps
         bool split; int cnt; blocks(l, split, cnt);
         while (nx.p == l) {
-            const int blk = strip_phys(split, nx.blk, cnt, h, rot);
+            const int blk = strip_phys(split, nx.blk, cnt, h, rot, PER);
             const bool det = a.dbg && l == a.sel && threadIdx.x == 0;
 #define DET(i) do { if (det) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
             DET(10);
@@ -730,7 +740,7 @@ __device__ __forceinline__ void strip_fwd_body(const StripFwdArgs<T>& a, const i
                 strip_epilogue<T, RT, NF>(acc, ax, ef, out, N, row0, blk, lane);
                 DET(13);
                 if (fin) { if (split || h == 0) strip_final_push<T, RT, NF>(a.finalF, out, N, sidx, blk, lane); }
-                else if (NF == 4 && split) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+                else if (split) duo_push<T, RT, NF>(a.duo, out, N, blk, seq & 1, lane);
             } else {                                              // the output unit: logits, loss, delta (column 0): item 0 = fragment 0 ..
                 if (RT == 1 && a.wlds[l] >= 0) strip_product<T, RT, NF>(acc, pb, in, wl + a.wlds[l], nkt, blk, lane);
                 else strip_product<T, RT, NF>(acc, pb, in, a.W[l], nkt, blk, lane);
@@ -752,7 +762,7 @@ __device__ __forceinline__ void strip_fwd_body(const StripFwdArgs<T>& a, const i
                 }
             }
         }
-        if (NF == 4 && split && !fin) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
+        if (split && !fin) { duo_swap<T, RT, NW>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, l < last, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (hidden && !fin) lds_barrier();
         STRIP_STAMP(2 + l);
         T* t = in; in = out; out = t;
@@ -782,8 +792,8 @@ __device__ __forceinline__ void strip_bwd_body(const StripBwdArgs<T>& a, const i
         if (nx.p < a.n) {
             bool sp; int cn; blocks(nx.p, sp, cn);
             const int wo = RT == 1 ? a.wlds[a.n - nx.p - 1] : -1;
-            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
-            else strip_prefetch<T, NF>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot), lane);
+            if (wo >= 0) strip_prefetch<T, NF>(pb, reinterpret_cast<const T*>(strip_smem) + (size_t)2 * RT * 16 * maxD + wo, a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot, PER), lane);
+            else strip_prefetch<T, NF>(pb, a.W[a.n - nx.p - 1], a.Dp[a.n - nx.p] / KS, strip_phys(sp, nx.blk, cn, h, rot, PER), lane);
         }
     };
     if (RT == 1) {                                               // the small products' weights -> LDS; in the backward launch they are the FIRST products
@@ -802,7 +812,7 @@ __device__ __forceinline__ void strip_bwd_body(const StripBwdArgs<T>& a, const i
         const int nkt = a.Dp[t] / KS, N = a.Dp[t - 1], q = a.n - t;
         bool split; int cnt; blocks(q, split, cnt);
         while (nx.p == q) {
-            const int blk = strip_phys(split, nx.blk, cnt, h, rot);
+            const int blk = strip_phys(split, nx.blk, cnt, h, rot, PER);
             EpiIpBwd<T> eb = a.eb[t - 1];
             if (a.duo.on && !split && h == 1) { eb.outT = nullptr; eb.out32 = nullptr; }   // a narrow product of a pair: both compute it, the first one stores it
             typename EpiIpBwd<T>::Aux ax[RT][NF];
@@ -812,10 +822,10 @@ __device__ __forceinline__ void strip_bwd_body(const StripBwdArgs<T>& a, const i
             nx = strip_next(a, nx, wave, false, h, PER, NW);
             prefetch_next();
             strip_epilogue<T, RT, NF>(acc, ax, eb, (t > 1 || !a.bottom) ? out : nullptr, N, row0, blk, lane);
-            if (NF == 4 && split && t > 1) duo_push<T, RT>(a.duo, out, N, blk, seq & 1, lane);
+            if (split && t > 1) duo_push<T, RT, NF>(a.duo, out, N, blk, seq & 1, lane);
             if (t == 1 && !a.bottom && (split || h == 0)) strip_final_push<T, RT, NF>(a.finalF, out, N, sidx, blk, lane);
         }
-        if (NF == 4 && split && t > 1) { duo_swap<T, RT>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
+        if (split && t > 1) { duo_swap<T, RT, NW>(a.duo, out, N, N / 64, h, seq & 1, seq + 1, true, a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr); ++seq; }
         if (t > 1) lds_barrier();
         STRIP_STAMP(2 + q);
         T* x = in; in = out; out = x;
@@ -1086,6 +1096,7 @@ struct ipnn_handle {
     int mask_side = 0;                               // IPNN_MASK_SIDE=1: the mask transposition on the side stream
     int group_xcd = 1;                               // IPNN_GROUP_XCD=0: tiles in launch order
     int strip_rot = 1, fwd_skip = 0;                 // IPNN_STRIP_ROT (0: every workgroup walks the blocks in the same order), IPNN_FWD_SKIP (diagnostics)
+    int wide_nf = 2, wide_nw = 8;                    // IPNN_WIDE=nf:nw -- items (16-column fragments) and waves of the wide (pair) launches: 2:8 (default), 4:8, 2:12
     bool wt = true;                                  // IPNN_WT=0: plain stores where the launches write through by default
     int tail_fuse = 1;                               // IPNN_TAIL_FUSE: training steps run the forward and the backward tail in one launch
     int tail_nf = 1;                                 // IPNN_TAIL_NF: 16-column fragments per item in the 16-example strips of the narrow tail (1 / 2 / 4)
@@ -1240,6 +1251,12 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
     if (strip) {
         if (!h->strip_attr) {                               // > 64 KiB of dynamic LDS needs the opt-in (once per handle = per device)
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            if constexpr (RT == 2) {
+                IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT, 2, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT, 2, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, RT, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            }
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_fwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             IHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_strip_bwd<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1312,6 +1329,12 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             s2.eo = sa.eo; s2.dbg = h->stamp_tail ? h->stamps : nullptr; s2.rot = h->strip_rot; s2.sel = -1; s2.has_out = 1; s2.finalF = nullptr; s2.warm = sa.warm;
             if (h->stamp_tail) s1.dbg = nullptr;
             s2.duo = StripDuo{0, nullptr, nullptr, 0, h->err_flag, 0, h->duo_min};
+            bool wide_done = false;
+            if constexpr (RT == 2) {                              // half-block items in the wide launch (IPNN_WIDE=nf:nw; measured: forward 59.8 -> 56.4 us at 2:8)
+                if (h->wide_nf == 2 && h->wide_nw == 12) { hipLaunchKernelGGL((k_ip_strip_fwd<T, RT, 2, 12>), dim3(nstrips * 2), dim3(64 * 12), strip_lds, h->st, s1, maxD); wide_done = true; }
+                else if (h->wide_nf == 2 && h->wide_nw == 8) { hipLaunchKernelGGL((k_ip_strip_fwd<T, RT, 2, 8>), dim3(nstrips * 2), dim3(64 * 8), strip_lds, h->st, s1, maxD); wide_done = true; }
+            }
+            if (!wide_done)
             hipLaunchKernelGGL((k_ip_strip_fwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, s1, maxD);
             const size_t wl2 = lds_weights(s2.Dp, s2.n, s2.wlds);
             if (fuse_tail) s2_fused = s2;
@@ -1369,6 +1392,12 @@ int ip_run(ipnn_handle* h, const int32_t* ids, const float* y, int B, const uint
             sB.dlast = (const T*)h->dl[cut - 1]; sB.n = cut;
             if (h->stamp_tail) sB.dbg = nullptr;
             sB.duo = StripDuo{1, h->duo_xch, h->duo_flags, ++h->duo_epoch, h->err_flag, h->duo_xch_wg, h->duo_min};
+            bool wide_done = false;
+            if constexpr (RT == 2) {
+                if (h->wide_nf == 2 && h->wide_nw == 12) { hipLaunchKernelGGL((k_ip_strip_bwd<T, RT, 2, 12>), dim3(nstrips * 2), dim3(64 * 12), strip_lds, h->st, sB, maxD); wide_done = true; }
+                else if (h->wide_nf == 2 && h->wide_nw == 8) { hipLaunchKernelGGL((k_ip_strip_bwd<T, RT, 2, 8>), dim3(nstrips * 2), dim3(64 * 8), strip_lds, h->st, sB, maxD); wide_done = true; }
+            }
+            if (!wide_done)
             hipLaunchKernelGGL((k_ip_strip_bwd<T, RT>), dim3(nstrips * 2), dim3(64 * STRIP_NW), strip_lds, h->st, sB, maxD);
         }
     } else {
@@ -1508,6 +1537,7 @@ int ipnn_create(const ipnn_cfg* cfg, ipnn_handle** out)
     if (const char* e = getenv("IPNN_IPF_NT")) h->ipf_nt = atoi(e) == 1024 ? 1024 : 512;
     if (const char* e = getenv("IPNN_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
     if (const char* e = getenv("IPNN_WT")) h->wt = atoi(e) != 0;
+    if (const char* e = getenv("IPNN_WIDE")) { int nf = 4, nw = 8; if (sscanf(e, "%d:%d", &nf, &nw) == 2 && ((nf == 2 && (nw == 8 || nw == 12)) || (nf == 4 && nw == 8))) { h->wide_nf = nf; h->wide_nw = nw; } }
     if (const char* e = getenv("IPNN_TAIL_NW")) h->tail_nw = atoi(e) == 16 ? 16 : 8;
     if (const char* e = getenv("IPNN_TAIL_NF")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->tail_nf = v; }
     if (const char* e = getenv("IPNN_GROUP_XCD")) h->group_xcd = atoi(e);

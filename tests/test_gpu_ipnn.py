@@ -376,10 +376,10 @@ def test_strip_pairs_are_bit_identical_to_single_strips(built, monkeypatch):
 
 @pytest.mark.parametrize("env", [{'IPNN_TAIL_NF': '4', 'IPNN_TAIL_NW': '8'}, {'IPNN_TAIL_NF': '2'}, {'IPNN_TAIL_NF': '1', 'IPNN_TAIL_NW': '8'},
                                  {'IPNN_TAIL_FUSE': '0'}, {'IPNN_TAIL_SPLIT': '0'}, {'IPNN_UPDATE_SIDE': '1'}, {'IPNN_IPF_NT': '512'},
-                                 {'IPNN_STRIP_WARM': '0'}, {'IPNN_WT': '0'}])
+                                 {'IPNN_STRIP_WARM': '0'}, {'IPNN_WT': '0'}, {'IPNN_WIDE': '4:8'}, {'IPNN_WIDE': '2:12'}])
 def test_launch_forms_of_the_step_are_bit_identical(built, monkeypatch, env):
     """The forms the FNN_IP_L7 step can be launched in -- the narrow tail's items of 4 / 2 / 1 fragments on 8 / 16 waves, both
-    passes' tails in one launch or two, no tail split at all, the dense update on the side stream with its join deferred to
+    passes' tails in one launch or two, no tail split at all, whole blocks or half blocks as the wide launches' items (8 or 12 waves), the dense update on the side stream with its join deferred to
     the next call, 512 / 1024 threads per workgroup in the gather, plain instead of write-through stores of the launches' outputs (a
     write-through store the next launch did not see in time would show here) -- only regroup the same sums: three train steps with dropout
     must leave logits, every dense tensor, b and the touched table rows BIT-equal to the default form's.  (The deferred update
